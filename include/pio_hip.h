@@ -1,0 +1,223 @@
+/*
+ * pio_hip.h -- C-ABI of libpio_hip.so: the MI355X (gfx950) PerceiverIO forward hot path.
+ *
+ * This is the drop-in boundary for the reference's perceiver_io/transformer_primitives.py and the
+ * encoder/decoder drivers of perceiver_io/perceiver.py.  The reference is pure Python and has no
+ * FFI of its own; each entry point below names the reference callable
+ * (file:line under /root/reference) whose arithmetic it replaces.  INTEGRATION.md shows the ctypes
+ * stub a maintainer of the reference would add to bind them.
+ *
+ * Conventions
+ *   - plain C, no torch / HIP types in signatures: `stream` is a hipStream_t passed as void*.
+ *   - every pointer is a DEVICE pointer owned by the caller; nothing is allocated or freed here and
+ *     there is no global mutable state => calls are thread-safe per (stream, workspace).
+ *   - scratch memory is caller-provided: query pio_*_workspace_bytes() first.
+ *   - tensors at the boundary are float32, last dimension contiguous; batch / row strides are given
+ *     in ELEMENTS (a batch stride of 0 is a broadcast view, e.g. the latent table of
+ *     position_encoding.py:117-121).
+ *   - masks are uint8 (0 = masked out), the storage of torch.bool.
+ *   - return value: PIO_OK (0) or a negative PIO_E_* code; no exceptions cross the ABI.
+ *   - matrix operands inside the library are fp16 (default) or bf16 with fp32 accumulation;
+ *     LayerNorm, softmax, bias, GELU and the residual stream are fp32.
+ */
+#ifndef PIO_HIP_H
+#define PIO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PIO_VERSION 100 /* 0.1.0 */
+
+enum {
+    PIO_OK = 0,
+    PIO_E_SHAPE = -1,     /* unsupported / inconsistent shape                       */
+    PIO_E_ALIGN = -2,     /* pointer or stride alignment requirement violated       */
+    PIO_E_ARCH = -3,      /* device is not gfx950                                   */
+    PIO_E_WORKSPACE = -4, /* workspace too small                                    */
+    PIO_E_LAUNCH = -5,    /* HIP launch error (hipGetLastError)                     */
+    PIO_E_ARG = -6        /* NULL / invalid argument                                */
+};
+
+/* operand dtype of the MFMA matrices (accumulation is always fp32) */
+enum { PIO_DT_F16 = 0, PIO_DT_BF16 = 1 };
+
+/* --- descriptors (host structs holding device pointers) --------------------------------------- */
+
+/* One nn.Linear packed for the kernels: `y = x W^T + b`, W is [out,in] in the reference
+ * (transformer_primitives.py:73-75,86 / 201-206).  Packed image: [n_pad][k_pad] operand dtype, K
+ * contiguous, zero padded; optional second image w_lo = W - float(w_hi) (two-pass weights). */
+typedef struct pio_linear_t {
+    const void *w_hi;
+    const void *w_lo;  /* NULL => single pass */
+    const float *bias; /* [n_pad] zero padded, or NULL */
+    int32_t n;         /* padded output features  (multiple of 8)  */
+    int32_t k;         /* padded input features   (multiple of 8)  */
+} pio_linear_t;
+
+/* nn.LayerNorm(c) (transformer_primitives.py:270-271, 365-367) */
+typedef struct pio_layernorm_t {
+    const float *gamma;
+    const float *beta;
+    int32_t c;
+    float eps;
+} pio_layernorm_t;
+
+/* Attention (transformer_primitives.py:34-88): proj_q/k/v + final.  Per-head widths are padded to
+ * multiples of 8 inside the packed images (dkp, dvp); logical widths are dk, dv. */
+typedef struct pio_attention_t {
+    pio_linear_t q, k, v, o;
+    int32_t heads;
+    int32_t dk, dv;   /* logical channels per head for q/k and v  */
+    int32_t dkp, dvp; /* padded (multiple of 8)                    */
+    int32_t q_in, k_in, v_in, out; /* logical channel counts (k_in == v_in inside Self/CrossAttention) */
+    int32_t dtype;    /* PIO_DT_*                                  */
+} pio_attention_t;
+
+/* MLP (transformer_primitives.py:183-216) */
+typedef struct pio_mlp_t {
+    pio_linear_t fc1, fc2;
+    int32_t in, hidden, out;
+    int32_t dtype;
+} pio_mlp_t;
+
+/* SelfAttention (transformer_primitives.py:219-297) */
+typedef struct pio_self_attention_t {
+    pio_layernorm_t ln1, ln2;
+    pio_attention_t attn;
+    pio_mlp_t mlp;
+} pio_self_attention_t;
+
+/* CrossAttention (transformer_primitives.py:300-406) */
+typedef struct pio_cross_attention_t {
+    pio_layernorm_t ln_q, ln_kv, ln2;
+    pio_attention_t attn;
+    pio_mlp_t mlp;
+    int32_t use_query_residual;
+} pio_cross_attention_t;
+
+/* A float32 activation tensor [B, T, C] at the boundary: element strides, C contiguous. */
+typedef struct pio_tensor3_t {
+    const float *data;
+    int64_t stride_b; /* 0 = broadcast over the batch */
+    int64_t stride_t;
+    int32_t B, T, C;
+} pio_tensor3_t;
+
+/* --- library / device ---------------------------------------------------------------------------- */
+int pio_version(void);
+/* 1 when the current HIP device is gfx950, 0 otherwise, <0 on error. */
+int pio_arch_ok(void);
+const char *pio_error_string(int code);
+
+/* --- weight packing (one-off, after load_state_dict) ------------------------------------------ */
+/* Round a channel count up to the packing granule (8). */
+int32_t pio_pad8(int32_t c);
+/* Bytes of ONE packed image (hi or lo) for out x in with per-head padding of rows / columns:
+ * rows = row_heads groups of (out/row_heads) padded to 8 each; columns likewise. */
+size_t pio_packed_weight_bytes(int32_t out, int32_t in, int32_t row_heads, int32_t col_heads);
+/* Pack W [out,in] fp32 (row stride ldw) into dst_hi (and dst_lo when non-NULL) starting at packed
+ * row `dst_row0` of an image with `k_pad` columns.  Rows are split in `row_heads` equal groups, each
+ * padded to a multiple of 8 rows; columns likewise with `col_heads`.  Padding is written as zeros.
+ * bias (may be NULL) is packed the same way into dst_bias[dst_row0...]. */
+int pio_pack_linear(const float *w, const float *bias, int32_t out, int32_t in, int64_t ldw,
+                    int32_t row_heads, int32_t col_heads, void *dst_hi, void *dst_lo, float *dst_bias,
+                    int32_t dst_row0, int32_t k_pad, int32_t dtype, void *stream);
+
+/* --- primitive kernels (exposed for tests and for callers that compose their own blocks) ------- */
+/* y[r, 0:c_pad] = operand_dtype( LN(x[r, 0:c]) ) with zero fill of [c, c_pad); ln == NULL => plain
+ * cast.  Rows are (b, t) of x.  Replaces nn.LayerNorm + the implicit cast in front of every GEMM. */
+int pio_layernorm_cast(const pio_tensor3_t *x, const pio_layernorm_t *ln, void *y, int32_t c_pad,
+                       int32_t dtype, void *stream);
+
+/* C = epilogue(alpha * A B^T): A [M,K], B [N,K] operand dtype, K contiguous (multiple of 8).
+ * Batched over z = zb*nh + zh with element strides; bias_mode 0 none / 1 per column / 2 per row;
+ * act 0 none / 1 exact-erf GELU (F.gelu, transformer_primitives.py:214); optional fp32 residual R
+ * added after the activation (row m of the flattened problem reads
+ * R + (m / r_rows_per_batch)*r_stride_b + (m % r_rows_per_batch)*ldr when r_rows_per_batch > 0);
+ * output fp32 (out_f32=1) or operand dtype with zero fill of columns [N, n_store). */
+typedef struct pio_gemm_t {
+    const void *A, *B;
+    const void *A_lo, *B_lo; /* optional second pass: C += A_lo*B^T resp. A*B_lo^T (two-pass weights) */
+    void *C;
+    int32_t M, N, K;
+    int64_t lda, ldb, ldc;
+    int32_t batch, nh;
+    int64_t sAb, sAh, sBb, sBh, sCb, sCh;
+    const float *bias;
+    int32_t bias_mode;
+    int32_t act;
+    float alpha;
+    const float *R;
+    int64_t ldr, r_stride_b;
+    int32_t r_rows_per_batch;
+    int32_t out_f32;
+    int32_t n_store;
+    int32_t dtype;
+} pio_gemm_t;
+int pio_gemm_nt(const pio_gemm_t *g, void *stream);
+
+/* P = softmax_j((S + bias) * scale) with masking, rows of length Tk (transformer_primitives.py:143-158,
+ * 168-175): S fp32 [B,H,Tq,Tk] (row stride lds), P operand dtype [B,H,Tq,ldp] zero filled to ldp.
+ * kv_mask [B,Tk], q_mask [B,Tq], full_mask [B,Tq,Tk] are optional uint8.  A row with no attendable key
+ * is written as zeros (the reference's "wipe").  bias optional fp32 [B,H,Tq,Tk]. */
+int pio_softmax_rows(const float *S, int64_t lds, void *P, int64_t ldp, int32_t B, int32_t H, int32_t Tq,
+                     int32_t Tk, float scale, const uint8_t *kv_mask, const uint8_t *q_mask,
+                     const uint8_t *full_mask, const float *bias, int32_t dtype, void *stream);
+
+/* --- blocks: the reference's nn.Module.forward calls ------------------------------------------ */
+/* Attention.forward (transformer_primitives.py:90-115 + attend 117-180).  inputs_k and inputs_v must
+ * have equal shapes.  out [B,Tq,out] fp32 contiguous.  probs_out (optional, fp32 [B,H,Tq,Tk]) receives
+ * the attention matrix (return_matrix=True). */
+size_t pio_attention_workspace_bytes(const pio_attention_t *a, int32_t B, int32_t Tq, int32_t Tk);
+int pio_attention_fwd(const pio_attention_t *a, const pio_tensor3_t *inputs_q, const pio_tensor3_t *inputs_k,
+                      const pio_tensor3_t *inputs_v, const uint8_t *kv_mask, const uint8_t *q_mask,
+                      const uint8_t *full_mask, const float *attention_bias, float *out, float *probs_out,
+                      void *workspace, size_t workspace_bytes, void *stream);
+
+/* MLP.forward (transformer_primitives.py:212-216). out [B,T,out] fp32 contiguous. */
+size_t pio_mlp_workspace_bytes(const pio_mlp_t *m, int64_t rows);
+int pio_mlp_fwd(const pio_mlp_t *m, const pio_tensor3_t *x, float *out, void *workspace,
+                size_t workspace_bytes, void *stream);
+
+/* SelfAttention.forward (transformer_primitives.py:275-297), no mask (perceiver.py:106 never passes one;
+ * masks, attention_bias [B,H,N,N] and probs_out [B,H,N,N] (return_matrix) are accepted for interface
+ * parity, all optional).  out [B,N,D] fp32 contiguous; out may alias x.data when x is contiguous. */
+size_t pio_self_attention_workspace_bytes(const pio_self_attention_t *s, int32_t B, int32_t N);
+int pio_self_attention_fwd(const pio_self_attention_t *s, const pio_tensor3_t *x, const uint8_t *kv_mask,
+                           const uint8_t *q_mask, const uint8_t *full_mask, const float *attention_bias,
+                           float *out, float *probs_out, void *workspace, size_t workspace_bytes, void *stream);
+
+/* CrossAttention.forward (transformer_primitives.py:371-406). out [B,Tq,q_in] fp32 contiguous. */
+size_t pio_cross_attention_workspace_bytes(const pio_cross_attention_t *c, int32_t B, int32_t Tq, int32_t Tk);
+int pio_cross_attention_fwd(const pio_cross_attention_t *c, const pio_tensor3_t *inputs_q,
+                            const pio_tensor3_t *inputs_kv, const uint8_t *kv_mask, const uint8_t *q_mask,
+                            const uint8_t *full_mask, const float *attention_bias, float *out, float *probs_out,
+                            void *workspace, size_t workspace_bytes, void *stream);
+
+/* PerceiverEncoder.forward (perceiver.py:98-107): cross-attend(latents <- inputs, key mask = input_mask)
+ * then num_blocks x [layers[0..L)] weight-shared self-attends.  `latents` is the query tensor the
+ * caller built (PerceiverEncoder.latents, perceiver.py:94-96: normally a stride-0 broadcast of the
+ * [N,D] table).  out [B,N,D] fp32 contiguous. */
+size_t pio_encoder_workspace_bytes(const pio_cross_attention_t *cross, const pio_self_attention_t *layers,
+                                   int32_t L, int32_t B, int32_t M, int32_t N);
+int pio_encoder_fwd(const pio_cross_attention_t *cross, const pio_self_attention_t *layers, int32_t L,
+                    int32_t num_blocks, const pio_tensor3_t *inputs, const pio_tensor3_t *latents,
+                    const uint8_t *input_mask, float *out, void *workspace, size_t workspace_bytes,
+                    void *stream);
+
+/* PerceiverDecoder.forward (perceiver.py:166-180): cross-attend(query <- latents, query mask) and the
+ * optional final nn.Linear (final == NULL => final_project=False).  out [B,Q,out_channels] fp32. */
+size_t pio_decoder_workspace_bytes(const pio_cross_attention_t *cross, const pio_linear_t *final_layer,
+                                   int32_t B, int32_t Q, int32_t N);
+int pio_decoder_fwd(const pio_cross_attention_t *cross, const pio_linear_t *final_layer, int32_t final_out,
+                    const pio_tensor3_t *query, const pio_tensor3_t *latents, const uint8_t *query_mask,
+                    float *out, void *workspace, size_t workspace_bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PIO_HIP_H */

@@ -1,0 +1,65 @@
+// extern "C" surface for the library/device queries and the primitive kernels (include/pio_hip.h).
+#include "pio_internal.h"
+
+#include <string.h>
+
+using namespace pio;
+
+extern "C" {
+
+int pio_version(void) { return PIO_VERSION; }
+
+int pio_arch_ok(void) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return PIO_E_LAUNCH;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return PIO_E_LAUNCH;
+    return strncmp(prop.gcnArchName, "gfx950", 6) == 0 ? 1 : 0;
+}
+
+const char *pio_error_string(int code) {
+    switch (code) {
+        case PIO_OK: return "ok";
+        case PIO_E_SHAPE: return "unsupported or inconsistent shape";
+        case PIO_E_ALIGN: return "pointer/stride alignment";
+        case PIO_E_ARCH: return "device is not gfx950";
+        case PIO_E_WORKSPACE: return "workspace too small";
+        case PIO_E_LAUNCH: return "HIP launch failed";
+        case PIO_E_ARG: return "invalid argument";
+        default: return "unknown error";
+    }
+}
+
+int32_t pio_pad8(int32_t c) { return pad8(c); }
+
+size_t pio_packed_weight_bytes(int32_t out, int32_t in, int32_t row_heads, int32_t col_heads) {
+    if (out <= 0 || in <= 0 || row_heads <= 0 || col_heads <= 0 || out % row_heads || in % col_heads) return 0;
+    return (size_t)row_heads * pad8(out / row_heads) * (size_t)col_heads * pad8(in / col_heads) * 2;
+}
+
+int pio_pack_linear(const float *w, const float *bias, int32_t out, int32_t in, int64_t ldw, int32_t row_heads,
+                    int32_t col_heads, void *dst_hi, void *dst_lo, float *dst_bias, int32_t dst_row0, int32_t k_pad,
+                    int32_t dtype, void *stream) {
+    return pack_linear_launch(w, bias, out, in, ldw, row_heads, col_heads, dst_hi, dst_lo, dst_bias, dst_row0, k_pad,
+                              dtype, (hipStream_t)stream);
+}
+
+int pio_layernorm_cast(const pio_tensor3_t *x, const pio_layernorm_t *ln, void *y, int32_t c_pad, int32_t dtype,
+                       void *stream) {
+    if (!x) return PIO_E_ARG;
+    return layernorm_cast_launch(*x, ln, y, c_pad, dtype, (hipStream_t)stream);
+}
+
+int pio_gemm_nt(const pio_gemm_t *g, void *stream) {
+    if (!g) return PIO_E_ARG;
+    return gemm_nt_launch(*g, (hipStream_t)stream);
+}
+
+int pio_softmax_rows(const float *S, int64_t lds, void *P, int64_t ldp, int32_t B, int32_t H, int32_t Tq, int32_t Tk,
+                     float scale, const uint8_t *kv_mask, const uint8_t *q_mask, const uint8_t *full_mask,
+                     const float *bias, int32_t dtype, void *stream) {
+    return softmax_rows_launch(S, lds, P, ldp, B, H, Tq, Tk, scale, kv_mask, q_mask, full_mask, bias, dtype, nullptr,
+                               (hipStream_t)stream);
+}
+
+}  // extern "C"

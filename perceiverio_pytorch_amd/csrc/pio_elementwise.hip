@@ -1,0 +1,284 @@
+// Memory-bound helpers of the hot path (gfx950): weight packing, LayerNorm + cast to the MFMA operand
+// dtype, row softmax with masking.  All arithmetic is fp32; only the stored operand is 16-bit.
+#include "pio_internal.h"
+
+namespace pio {
+
+// =====================================================================================================
+// pack_linear: W [out,in] fp32 -> packed [rows_p][k_pad] 16-bit (hi) + optional lo = W - float(hi).
+// Head-padded rows / columns: group g of d logical entries occupies packed entries [g*dp, g*dp + d).
+// =====================================================================================================
+template <int DT>
+__global__ void pack_linear_kernel(const float *__restrict__ w, const float *__restrict__ bias, int out, int in,
+                                   int64_t ldw, int dr, int drp, int rows_p, int dc, int dcp, int cols_used,
+                                   typename Op<DT>::T *hi, typename Op<DT>::T *lo, float *dst_bias, int dst_row0,
+                                   int k_pad) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = (int64_t)rows_p * k_pad;
+    if (idx >= total) return;
+    const int rp = (int)(idx / k_pad);
+    const int cp = (int)(idx % k_pad);
+    const int hr = rp / drp, jr = rp % drp;
+    float v = 0.f;
+    const bool rvalid = jr < dr;
+    if (rvalid && cp < cols_used) {
+        const int hc = cp / dcp, jc = cp % dcp;
+        if (jc < dc) v = w[(int64_t)(hr * dr + jr) * ldw + (hc * dc + jc)];
+    }
+    const typename Op<DT>::T h = Op<DT>::from_f32(v);
+    const int64_t o = (int64_t)(dst_row0 + rp) * k_pad + cp;
+    hi[o] = h;
+    if (lo) lo[o] = Op<DT>::from_f32(v - Op<DT>::to_f32(h));
+    if (cp == 0 && dst_bias) dst_bias[dst_row0 + rp] = (rvalid && bias) ? bias[hr * dr + jr] : 0.f;
+}
+
+int pack_linear_launch(const float *w, const float *bias, int out, int in, int64_t ldw, int row_heads,
+                       int col_heads, void *dst_hi, void *dst_lo, float *dst_bias, int dst_row0, int k_pad,
+                       int dtype, hipStream_t s) {
+    if (!w || !dst_hi) return PIO_E_ARG;
+    if (out <= 0 || in <= 0 || row_heads <= 0 || col_heads <= 0) return PIO_E_SHAPE;
+    if (out % row_heads || in % col_heads) return PIO_E_SHAPE;
+    const int dr = out / row_heads, drp = pad8(dr);
+    const int dc = in / col_heads, dcp = pad8(dc);
+    const int rows_p = row_heads * drp;
+    const int cols_used = col_heads * dcp;
+    if (cols_used > k_pad || (k_pad % 8)) return PIO_E_SHAPE;
+    const int64_t total = (int64_t)rows_p * k_pad;
+    const int threads = 256;
+    const unsigned blocks = (unsigned)((total + threads - 1) / threads);
+    if (dtype == PIO_DT_F16)
+        hipLaunchKernelGGL((pack_linear_kernel<PIO_DT_F16>), dim3(blocks), dim3(threads), 0, s, w, bias, out, in, ldw,
+                           dr, drp, rows_p, dc, dcp, cols_used, (_Float16 *)dst_hi, (_Float16 *)dst_lo, dst_bias,
+                           dst_row0, k_pad);
+    else if (dtype == PIO_DT_BF16)
+        hipLaunchKernelGGL((pack_linear_kernel<PIO_DT_BF16>), dim3(blocks), dim3(threads), 0, s, w, bias, out, in,
+                           ldw, dr, drp, rows_p, dc, dcp, cols_used, (__bf16 *)dst_hi, (__bf16 *)dst_lo, dst_bias,
+                           dst_row0, k_pad);
+    else
+        return PIO_E_ARG;
+    return launch_status();
+}
+
+// =====================================================================================================
+// layernorm_cast: one 64-lane wave per row; mean, centred variance (two-pass, like ATen), affine, cast.
+// The row is re-read from L1 for the second and third pass (a row is <= a few KiB and owned by one wave),
+// so HBM sees it once.  Vector path (float4 / 8-byte stores) when C % 4 == 0 and rows are 16-B aligned.
+// =====================================================================================================
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+template <int DT, bool VEC, bool NORM>
+__global__ __launch_bounds__(256) void layernorm_cast_kernel(const float *__restrict__ x, int64_t stride_b,
+                                                             int64_t stride_t, int T, int64_t rows, int C,
+                                                             const float *__restrict__ gamma,
+                                                             const float *__restrict__ beta, float eps,
+                                                             typename Op<DT>::T *__restrict__ y, int c_pad) {
+    typedef typename Op<DT>::T OT;
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float *xr = x + (row / T) * stride_b + (row % T) * stride_t;
+    OT *yr = y + row * (int64_t)c_pad;
+    float mean = 0.f, rstd = 1.f;
+    if (NORM) {
+        float s = 0.f;
+        if (VEC) {
+            for (int i = lane * 4; i < C; i += 256) {
+                const f32x4 v = *(const f32x4 *)(xr + i);
+                s += (v[0] + v[1]) + (v[2] + v[3]);
+            }
+        } else {
+            for (int i = lane; i < C; i += 64) s += xr[i];
+        }
+        mean = wave_sum(s) / (float)C;
+        float q = 0.f;
+        if (VEC) {
+            for (int i = lane * 4; i < C; i += 256) {
+                const f32x4 v = *(const f32x4 *)(xr + i);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float d = v[j] - mean;
+                    q += d * d;
+                }
+            }
+        } else {
+            for (int i = lane; i < C; i += 64) {
+                const float d = xr[i] - mean;
+                q += d * d;
+            }
+        }
+        rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
+    }
+    if (VEC) {
+        for (int i = lane * 4; i < c_pad; i += 256) {
+            typename Op<DT>::V4 o;
+            if (i < C) {
+                const f32x4 v = *(const f32x4 *)(xr + i);
+                if (NORM) {
+                    const f32x4 g = *(const f32x4 *)(gamma + i);
+                    const f32x4 b = *(const f32x4 *)(beta + i);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = Op<DT>::from_f32((v[j] - mean) * rstd * g[j] + b[j]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = Op<DT>::from_f32(v[j]);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = Op<DT>::from_f32(0.f);
+            }
+            *(typename Op<DT>::V4 *)(yr + i) = o;
+        }
+    } else {
+        for (int i = lane; i < c_pad; i += 64) {
+            float v = 0.f;
+            if (i < C) {
+                v = xr[i];
+                if (NORM) v = (v - mean) * rstd * gamma[i] + beta[i];
+            }
+            yr[i] = Op<DT>::from_f32(v);
+        }
+    }
+}
+
+int layernorm_cast_launch(const pio_tensor3_t &x, const pio_layernorm_t *ln, void *y, int c_pad, int dtype,
+                          hipStream_t s) {
+    if (!x.data || !y) return PIO_E_ARG;
+    if (x.B <= 0 || x.T <= 0 || x.C <= 0 || c_pad < x.C || (c_pad % 8)) return PIO_E_SHAPE;
+    if (ln && (ln->c != x.C || !ln->gamma || !ln->beta)) return PIO_E_SHAPE;
+    const int64_t rows = (int64_t)x.B * x.T;
+    const bool vec = (x.C % 4 == 0) && (((uintptr_t)x.data & 15) == 0) && (x.stride_b % 4 == 0) &&
+                     (x.stride_t % 4 == 0) && (((uintptr_t)y & 7) == 0) &&
+                     (!ln || ((((uintptr_t)ln->gamma) & 15) == 0 && (((uintptr_t)ln->beta) & 15) == 0));
+    const unsigned blocks = (unsigned)((rows + 3) / 4);
+    const float eps = ln ? ln->eps : 0.f;
+    const float *g = ln ? ln->gamma : nullptr;
+    const float *b = ln ? ln->beta : nullptr;
+#define PIO_LN_LAUNCH(DTV, VECV, NORMV)                                                                          \
+    hipLaunchKernelGGL((layernorm_cast_kernel<DTV, VECV, NORMV>), dim3(blocks), dim3(256), 0, s, x.data,          \
+                       x.stride_b, x.stride_t, x.T, rows, x.C, g, b, eps, (typename Op<DTV>::T *)y, c_pad)
+    if (dtype == PIO_DT_F16) {
+        if (ln) { if (vec) PIO_LN_LAUNCH(PIO_DT_F16, true, true); else PIO_LN_LAUNCH(PIO_DT_F16, false, true); }
+        else    { if (vec) PIO_LN_LAUNCH(PIO_DT_F16, true, false); else PIO_LN_LAUNCH(PIO_DT_F16, false, false); }
+    } else if (dtype == PIO_DT_BF16) {
+        if (ln) { if (vec) PIO_LN_LAUNCH(PIO_DT_BF16, true, true); else PIO_LN_LAUNCH(PIO_DT_BF16, false, true); }
+        else    { if (vec) PIO_LN_LAUNCH(PIO_DT_BF16, true, false); else PIO_LN_LAUNCH(PIO_DT_BF16, false, false); }
+    } else {
+        return PIO_E_ARG;
+    }
+#undef PIO_LN_LAUNCH
+    return launch_status();
+}
+
+// =====================================================================================================
+// softmax_rows: P = softmax_j((S + bias) * scale) over valid keys; masked keys get exactly 0 (the
+// reference's exp(-1e30 - max) underflows to 0 in fp32), rows without any valid key are zeros ("wipe",
+// transformer_primitives.py:168-175).  One wave per row for short rows, one 256-thread block per row
+// for long ones (M up to 182 528 in the optical-flow configuration).
+// =====================================================================================================
+struct SoftmaxParams {
+    const float *S;
+    int64_t lds;
+    void *P;
+    int64_t ldp;
+    int B, H, Tq, Tk;
+    float scale;
+    const uint8_t *kv_mask, *q_mask, *full_mask;
+    const float *bias;
+    float *probs;
+};
+
+template <int DT, int WAVES_PER_ROW>
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const SoftmaxParams p) {
+    typedef typename Op<DT>::T OT;
+    __shared__ float red[8];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int64_t rows = (int64_t)p.B * p.H * p.Tq;
+    int64_t row;
+    int t0, tstep;
+    if (WAVES_PER_ROW == 1) {
+        row = (int64_t)blockIdx.x * 4 + wave;
+        t0 = lane;
+        tstep = 64;
+    } else {
+        row = blockIdx.x;
+        t0 = threadIdx.x;
+        tstep = 256;
+    }
+    const bool active = row < rows;
+    if (WAVES_PER_ROW == 1 && !active) return;
+    const int i = (int)(row % p.Tq);
+    const int b = (int)(row / ((int64_t)p.H * p.Tq));
+    const float *s = p.S + row * p.lds;
+    const float *bi = p.bias ? p.bias + row * (int64_t)p.Tk : nullptr;
+    const uint8_t *km = p.kv_mask ? p.kv_mask + (int64_t)b * p.Tk : nullptr;
+    const uint8_t *fm = p.full_mask ? p.full_mask + ((int64_t)b * p.Tq + i) * p.Tk : nullptr;
+    const bool qok = p.q_mask ? p.q_mask[(int64_t)b * p.Tq + i] != 0 : true;
+    OT *pr = (OT *)p.P + row * p.ldp;
+    float *po = p.probs ? p.probs + row * (int64_t)p.Tk : nullptr;
+
+    auto valid = [&](int j) -> bool { return qok && (!km || km[j]) && (!fm || fm[j]); };
+    auto score = [&](int j) -> float { return (s[j] + (bi ? bi[j] : 0.f)) * p.scale; };
+
+    float m = -INFINITY;
+    for (int j = t0; j < p.Tk; j += tstep)
+        if (valid(j)) m = fmaxf(m, score(j));
+    m = wave_max(m);
+    if (WAVES_PER_ROW > 1) {
+        if (lane == 0) red[wave] = m;
+        __syncthreads();
+        m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        __syncthreads();
+    }
+    const bool any = m > -INFINITY;  // wave-uniform
+    float sum = 0.f;
+    if (any)
+        for (int j = t0; j < p.Tk; j += tstep)
+            if (valid(j)) sum += __expf(score(j) - m);
+    sum = wave_sum(sum);
+    if (WAVES_PER_ROW > 1) {
+        if (lane == 0) red[4 + wave] = sum;
+        __syncthreads();
+        sum = (red[4] + red[5]) + (red[6] + red[7]);
+    }
+    const float inv = any ? 1.f / sum : 0.f;
+    const float uni = 1.f / (float)p.Tk;
+    for (int j = t0; j < (int)p.ldp; j += tstep) {
+        float v = 0.f;
+        if (j < p.Tk && any && valid(j)) v = __expf(score(j) - m) * inv;
+        pr[j] = Op<DT>::from_f32(v);
+        if (po && j < p.Tk) po[j] = any ? v : uni;  // reference returns the un-wiped (uniform) matrix
+    }
+}
+
+int softmax_rows_launch(const float *S, int64_t lds, void *P, int64_t ldp, int B, int H, int Tq, int Tk,
+                        float scale, const uint8_t *kv_mask, const uint8_t *q_mask, const uint8_t *full_mask,
+                        const float *bias, int dtype, float *probs_out, hipStream_t s) {
+    if (!S || !P) return PIO_E_ARG;
+    if (B <= 0 || H <= 0 || Tq <= 0 || Tk <= 0 || ldp < Tk || lds < Tk) return PIO_E_SHAPE;
+    SoftmaxParams p{S, lds, P, ldp, B, H, Tq, Tk, scale, kv_mask, q_mask, full_mask, bias, probs_out};
+    const int64_t rows = (int64_t)B * H * Tq;
+    if (Tk <= 2048) {
+        const unsigned blocks = (unsigned)((rows + 3) / 4);
+        if (dtype == PIO_DT_F16) hipLaunchKernelGGL((softmax_rows_kernel<PIO_DT_F16, 1>), dim3(blocks), dim3(256), 0, s, p);
+        else if (dtype == PIO_DT_BF16) hipLaunchKernelGGL((softmax_rows_kernel<PIO_DT_BF16, 1>), dim3(blocks), dim3(256), 0, s, p);
+        else return PIO_E_ARG;
+    } else {
+        const unsigned blocks = (unsigned)rows;
+        if (dtype == PIO_DT_F16) hipLaunchKernelGGL((softmax_rows_kernel<PIO_DT_F16, 4>), dim3(blocks), dim3(256), 0, s, p);
+        else if (dtype == PIO_DT_BF16) hipLaunchKernelGGL((softmax_rows_kernel<PIO_DT_BF16, 4>), dim3(blocks), dim3(256), 0, s, p);
+        else return PIO_E_ARG;
+    }
+    return launch_status();
+}
+
+}  // namespace pio

@@ -1,0 +1,256 @@
+// NT GEMM on gfx950 matrix cores:  C = epilogue(alpha * A B^T)
+//   A [M,K], B [N,K]: 16-bit operands (fp16 / bf16), K contiguous -- exactly the layout of an
+//   nn.Linear weight ([out,in], transformer_primitives.py:73-75) and of a row-major activation, so
+//   neither operand is ever transposed in memory.
+//   Replaces F.linear / matmul at transformer_primitives.py:93-95, 110, 138, 163, 213-215.
+//
+// v1 structure (128x128x64 tile, 4 waves as 2x2, one 64x64 sub-tile per wave, MFMA 16x16x32):
+//   * both operand tiles go HBM -> LDS by LDS-DMA (global_load_lds_dwordx4): the LDS image is lane-linear,
+//     the XOR swizzle is applied to the per-lane SOURCE address and again on the ds_read_b128 side;
+//   * rows past M / N are clamped (their results are never stored), 8-element K chunks past K read a
+//     16-byte zero block, so no operand needs padding beyond a multiple of 8;
+//   * double-buffered, ONE barrier per K step: the DMA of tile t+1 is in flight while tile t is multiplied;
+//   * the MFMA is issued as (B-fragment, A-fragment) so that each lane ends up with 4 CONSECUTIVE output
+//     columns of one row: bias / residual / stores are 8- or 16-byte vectors;
+//   * optional second K sweep with one operand replaced by its *_lo image (W = W_hi + W_lo, the "x2w"
+//     precision policy) accumulating into the same registers.
+#include "pio_internal.h"
+
+namespace pio {
+
+__device__ __attribute__((aligned(16))) uint32_t g_zero_chunk[4] = {0, 0, 0, 0};
+
+struct GemmParams {
+    const void *A, *B, *A2, *B2;  // second-pass operands (== A / B unless a *_lo image is given)
+    void *C;
+    int M, N, K;
+    int64_t lda, ldb, ldc;
+    int nh;
+    int64_t sAb, sAh, sBb, sBh, sCb, sCh;
+    const float *bias;
+    int bias_mode, act;
+    float alpha;
+    const float *R;
+    int64_t ldr, r_stride_b;
+    int r_rows;
+    int out_f32, n_store;
+    int tiles_n;
+    int vec_ok;  // C (and R) rows are 16-byte (fp32) / 8-byte (16-bit) aligned for 4-column vectors
+};
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand tile
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+template <int DT, bool LO>
+__global__ __launch_bounds__(256) void gemm_nt_128(const GemmParams p) {
+    typedef typename Op<DT>::T T;
+    typedef typename Op<DT>::V8 V8;
+    __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];  // A0 A1 B0 B1
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int tile_n = blockIdx.x % p.tiles_n;
+    const int tile_m = blockIdx.x / p.tiles_n;
+    const int z = blockIdx.y;
+    const int zb = z / p.nh, zh = z % p.nh;
+
+    const T *A = (const T *)p.A + zb * p.sAb + zh * p.sAh;
+    const T *B = (const T *)p.B + zb * p.sBb + zh * p.sBh;
+    const T *A2 = LO ? (const T *)p.A2 + zb * p.sAb + zh * p.sAh : nullptr;
+    const T *B2 = LO ? (const T *)p.B2 + zb * p.sBb + zh * p.sBh : nullptr;
+
+    // ---- staging addresses: wave w, piece i covers tile rows (w*4+i)*8 .. +8, lane -> (row, 16-B slot)
+    const int srow = lane >> 3;
+    const int sslot = lane & 7;
+    const T *a_src[4];
+    const T *b_src[4];
+    const T *a2_src[4];
+    const T *b2_src[4];
+    int s_koff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = (wave * 4 + i) * 8 + srow;          // row inside the tile
+        const int c = sslot ^ ((r >> 1) & 7);              // source chunk that lands in this slot
+        s_koff[i] = c * 8;
+        int gm = tile_m * BM + r;
+        gm = gm < p.M ? gm : p.M - 1;
+        int gn = tile_n * BN + r;
+        gn = gn < p.N ? gn : p.N - 1;
+        a_src[i] = A + (int64_t)gm * p.lda + c * 8;
+        b_src[i] = B + (int64_t)gn * p.ldb + c * 8;
+        a2_src[i] = LO ? A2 + (int64_t)gm * p.lda + c * 8 : nullptr;
+        b2_src[i] = LO ? B2 + (int64_t)gn * p.ldb + c * 8 : nullptr;
+    }
+    const T *zsrc = (const T *)g_zero_chunk;
+
+    const int nk1 = (p.K + BK - 1) / BK;
+    const int nk = LO ? 2 * nk1 : nk1;
+
+    auto stage = [&](int kt, int buf) {
+        const bool lo = LO && kt >= nk1;
+        const int k0 = (lo ? kt - nk1 : kt) * BK;
+        char *abase = smem + buf * TILE_BYTES;
+        char *bbase = smem + (2 + buf) * TILE_BYTES;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool kin = (k0 + s_koff[i]) < p.K;
+            const T *sa = kin ? ((lo ? a2_src[i] : a_src[i]) + k0) : zsrc;
+            const T *sb = kin ? ((lo ? b2_src[i] : b_src[i]) + k0) : zsrc;
+            const int piece = (wave * 4 + i) * 1024;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)sa,
+                                             (__attribute__((address_space(3))) void *)(abase + piece), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)sb,
+                                             (__attribute__((address_space(3))) void *)(bbase + piece), 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // ---- fragment read addresses (bytes inside a tile): row = base16 + (lane&15), chunk = ks*4 + (lane>>4)
+    const int frow = lane & 15;
+    const int fswz = (frow >> 1) & 7;
+    const int fchunk = lane >> 4;
+    int a_off[4], b_off[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        a_off[i] = (wm * 64 + i * 16 + frow) * 128;
+        b_off[i] = (wn * 64 + i * 16 + frow) * 128;
+    }
+
+    stage(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
+        const char *abase = smem + (kt & 1) * TILE_BYTES;
+        const char *bbase = smem + (2 + (kt & 1)) * TILE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int coff = ((ks * 4 + fchunk) ^ fswz) << 4;
+            V8 af[4], bf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                af[i] = *(const V8 *)(abase + a_off[i] + coff);
+                bf[i] = *(const V8 *)(bbase + b_off[i] + coff);
+            }
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = Op<DT>::mfma16(bf[ni], af[mi], acc[mi][ni]);
+        }
+    }
+
+    // ---- epilogue: lane holds C[m][n0..n0+3], m = ..+(lane&15), n0 = ..+4*(lane>>4)
+    const int64_t coffz = zb * p.sCb + zh * p.sCh;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        const int m = tile_m * BM + wm * 64 + mi * 16 + (lane & 15);
+        if (m >= p.M) continue;
+        const float *rrow = nullptr;
+        if (p.R) {
+            if (p.r_rows > 0)
+                rrow = p.R + (int64_t)(m / p.r_rows) * p.r_stride_b + (int64_t)(m % p.r_rows) * p.ldr;
+            else
+                rrow = p.R + (int64_t)m * p.ldr;
+        }
+        const float bias_m = (p.bias_mode == 2) ? p.bias[m] : 0.f;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const int n0 = tile_n * BN + wn * 64 + ni * 16 + 4 * (lane >> 4);
+            if (n0 >= p.n_store) continue;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + r;
+                float x = acc[mi][ni][r] * p.alpha;
+                if (n < p.N) {
+                    if (p.bias_mode == 1) x += p.bias[n];
+                    x += bias_m;
+                    if (p.act == 1) x = gelu_erf(x);
+                    if (rrow) x += rrow[n];
+                } else {
+                    x = 0.f;
+                }
+                v[r] = x;
+            }
+            if (p.out_f32) {
+                float *crow = (float *)p.C + coffz + (int64_t)m * p.ldc;
+                if (p.vec_ok && n0 + 3 < p.n_store) {
+                    *(f32x4 *)(crow + n0) = (f32x4){v[0], v[1], v[2], v[3]};
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (n0 + r < p.n_store) crow[n0 + r] = v[r];
+                }
+            } else {
+                T *crow = (T *)p.C + coffz + (int64_t)m * p.ldc;
+                if (p.vec_ok && n0 + 3 < p.n_store) {
+                    typename Op<DT>::V4 h = {Op<DT>::from_f32(v[0]), Op<DT>::from_f32(v[1]), Op<DT>::from_f32(v[2]),
+                                             Op<DT>::from_f32(v[3])};
+                    *(typename Op<DT>::V4 *)(crow + n0) = h;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (n0 + r < p.n_store) crow[n0 + r] = Op<DT>::from_f32(v[r]);
+                }
+            }
+        }
+    }
+}
+
+int gemm_nt_launch(const pio_gemm_t &g, hipStream_t s) {
+    if (!g.A || !g.B || !g.C) return PIO_E_ARG;
+    if (g.M <= 0 || g.N <= 0 || g.K <= 0 || g.batch <= 0 || g.nh <= 0) return PIO_E_SHAPE;
+    if (g.K % 8) return PIO_E_SHAPE;
+    if (g.batch % g.nh) return PIO_E_SHAPE;
+    if ((g.lda % 8) || (g.ldb % 8) || (g.sAb % 8) || (g.sAh % 8) || (g.sBb % 8) || (g.sBh % 8)) return PIO_E_ALIGN;
+    if (((uintptr_t)g.A & 15) || ((uintptr_t)g.B & 15) || ((uintptr_t)g.A_lo & 15) || ((uintptr_t)g.B_lo & 15))
+        return PIO_E_ALIGN;
+    if (g.batch > 65535) return PIO_E_SHAPE;
+    if (g.bias_mode && !g.bias) return PIO_E_ARG;
+    if (g.dtype != PIO_DT_F16 && g.dtype != PIO_DT_BF16) return PIO_E_ARG;
+
+    GemmParams p;
+    p.A = g.A; p.B = g.B; p.C = g.C;
+    p.A2 = g.A_lo ? g.A_lo : g.A;
+    p.B2 = g.B_lo ? g.B_lo : g.B;
+    p.M = g.M; p.N = g.N; p.K = g.K;
+    p.lda = g.lda; p.ldb = g.ldb; p.ldc = g.ldc;
+    p.nh = g.nh;
+    p.sAb = g.sAb; p.sAh = g.sAh; p.sBb = g.sBb; p.sBh = g.sBh; p.sCb = g.sCb; p.sCh = g.sCh;
+    p.bias = g.bias; p.bias_mode = g.bias_mode; p.act = g.act; p.alpha = g.alpha;
+    p.R = g.R; p.ldr = g.ldr; p.r_stride_b = g.r_stride_b; p.r_rows = g.r_rows_per_batch;
+    p.out_f32 = g.out_f32;
+    p.n_store = g.n_store > g.N ? g.n_store : g.N;
+    if (p.n_store > g.ldc) return PIO_E_SHAPE;
+    p.tiles_n = (p.n_store + BN - 1) / BN;
+    const int tiles_m = (g.M + BM - 1) / BM;
+    const size_t esz = g.out_f32 ? 4 : 2;
+    const size_t valign = g.out_f32 ? 16 : 8;
+    bool vec = (((uintptr_t)g.C) % valign == 0) && ((g.ldc * esz) % valign == 0) && ((g.sCb * esz) % valign == 0) &&
+               ((g.sCh * esz) % valign == 0);
+    p.vec_ok = vec ? 1 : 0;
+
+    dim3 grid((unsigned)(tiles_m * p.tiles_n), (unsigned)g.batch, 1);
+    dim3 block(256, 1, 1);
+    const bool lo = g.B_lo != nullptr || g.A_lo != nullptr;
+    if (g.dtype == PIO_DT_F16) {
+        if (lo) hipLaunchKernelGGL((gemm_nt_128<PIO_DT_F16, true>), grid, block, 0, s, p);
+        else    hipLaunchKernelGGL((gemm_nt_128<PIO_DT_F16, false>), grid, block, 0, s, p);
+    } else {
+        if (lo) hipLaunchKernelGGL((gemm_nt_128<PIO_DT_BF16, true>), grid, block, 0, s, p);
+        else    hipLaunchKernelGGL((gemm_nt_128<PIO_DT_BF16, false>), grid, block, 0, s, p);
+    }
+    return launch_status();
+}
+
+}  // namespace pio

@@ -1,0 +1,79 @@
+// Internal declarations shared by the HIP translation units of libpio_hip.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#include "../../include/pio_hip.h"
+
+namespace pio {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// Operand-dtype traits: the 16-bit type fed to MFMA.
+template <int DT> struct Op;
+template <> struct Op<PIO_DT_F16> {
+    typedef _Float16 T;
+    typedef f16x8 V8;
+    typedef f16x4 V4;
+    static __device__ __forceinline__ T from_f32(float x) { return (T)x; }
+    static __device__ __forceinline__ float to_f32(T x) { return (float)x; }
+    static __device__ __forceinline__ f32x4 mfma16(V8 a, V8 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ f32x16 mfma32(V8 a, V8 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct Op<PIO_DT_BF16> {
+    typedef __bf16 T;
+    typedef bf16x8 V8;
+    typedef bf16x4 V4;
+    static __device__ __forceinline__ T from_f32(float x) { return (T)x; }  // v_cvt_pk_bf16_f32 (RNE, NaN kept)
+    static __device__ __forceinline__ float to_f32(T x) { return (float)x; }
+    static __device__ __forceinline__ f32x4 mfma16(V8 a, V8 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ f32x16 mfma32(V8 a, V8 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+};
+
+static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+static inline int pad8(int c) { return (c + 7) & ~7; }
+
+// carve helper for caller-provided workspaces (256-byte aligned pieces)
+struct Carver {
+    char *base;
+    size_t off;
+    explicit Carver(void *p) : base((char *)p), off(0) {}
+    void *take(size_t bytes) {
+        void *r = base ? base + off : nullptr;
+        off += (size_t)round_up((int64_t)bytes, 256);
+        return r;
+    }
+};
+
+static inline int launch_status() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? PIO_OK : PIO_E_LAUNCH;
+}
+
+// ---- internal launchers (defined in the .hip files) ---------------------------------------------
+int gemm_nt_launch(const pio_gemm_t &g, hipStream_t s);
+int layernorm_cast_launch(const pio_tensor3_t &x, const pio_layernorm_t *ln, void *y, int c_pad, int dtype,
+                          hipStream_t s);
+int softmax_rows_launch(const float *S, int64_t lds, void *P, int64_t ldp, int B, int H, int Tq, int Tk,
+                        float scale, const uint8_t *kv_mask, const uint8_t *q_mask, const uint8_t *full_mask,
+                        const float *bias, int dtype, float *probs_out, hipStream_t s);
+int pack_linear_launch(const float *w, const float *bias, int out, int in, int64_t ldw, int row_heads,
+                       int col_heads, void *dst_hi, void *dst_lo, float *dst_bias, int dst_row0, int k_pad,
+                       int dtype, hipStream_t s);
+
+}  // namespace pio

@@ -1,0 +1,159 @@
+"""Host-side plumbing between torch tensors and the C-ABI: precision policy, packed-weight images,
+descriptors, workspaces.  PyTorch is used for device memory and streams only."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from . import _lib as L
+
+# ------------------------------------------------------------------------------------------------
+# precision policy: operand dtype of the MFMA matrices x number of weight passes.
+#   fp16     one pass, fp16 operands                      (fastest that can meet 1e-3)
+#   fp16x2w  W = W_hi + W_lo, two passes on weight GEMMs  (most accurate)
+#   bf16 / bf16x2w likewise with bf16 operands (wider range, 8x coarser mantissa)
+# ------------------------------------------------------------------------------------------------
+_POLICIES = {"fp16": (L.PIO_DT_F16, False), "fp16x2w": (L.PIO_DT_F16, True),
+             "bf16": (L.PIO_DT_BF16, False), "bf16x2w": (L.PIO_DT_BF16, True)}
+_policy = os.environ.get("PIO_PRECISION", "fp16x2w")
+if _policy not in _POLICIES:
+    raise ValueError(f"PIO_PRECISION={_policy!r} not in {sorted(_POLICIES)}")
+
+
+def set_precision_policy(name: str) -> None:
+    global _policy
+    if name not in _POLICIES:
+        raise ValueError(f"unknown precision policy {name!r}; choose from {sorted(_POLICIES)}")
+    _policy = name
+
+
+def get_precision_policy() -> str:
+    return _policy
+
+
+def policy_dtype(name: Optional[str] = None) -> Tuple[int, bool]:
+    return _POLICIES[name or _policy]
+
+
+def pad8(c: int) -> int:
+    return (c + 7) & ~7
+
+
+def require_device(t: torch.Tensor, what: str) -> None:
+    if not t.is_cuda:
+        raise L.PioError(f"{what}: perceiverio_pytorch_amd computes on an MI355X (HIP) device only; got a "
+                         f"{t.device} tensor. There is no CPU or eager fallback.")
+
+
+def stream_ptr(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+# ------------------------------------------------------------------------------------------------
+# tensors at the boundary
+# ------------------------------------------------------------------------------------------------
+def as_f32_3d(t: torch.Tensor) -> torch.Tensor:
+    """float32, last dim contiguous, 3-D; broadcast (stride-0) batch views are kept as views."""
+    if t.dim() != 3:
+        raise ValueError(f"expected a [B, T, C] tensor, got {tuple(t.shape)}")
+    if t.dtype != torch.float32:
+        t = t.float()
+    if t.stride(2) != 1 and t.shape[2] != 1:
+        t = t.contiguous()
+    if t.stride(1) < t.shape[2] and t.shape[1] > 1:    # exotic row-overlapping views
+        t = t.contiguous()
+    return t
+
+
+def tensor3(t: torch.Tensor) -> L.Tensor3:
+    B, T, Cc = t.shape
+    sb = t.stride(0) if B > 1 else T * Cc
+    st = t.stride(1) if T > 1 else Cc
+    return L.Tensor3(t.data_ptr(), sb, st, B, T, Cc)
+
+
+def mask_u8(m: Optional[torch.Tensor], shape, device) -> Tuple[Optional[torch.Tensor], Optional[int]]:
+    """bool/any mask -> contiguous uint8 tensor on `device` (kept alive by the caller) + pointer."""
+    if m is None:
+        return None, None
+    if tuple(m.shape) != tuple(shape):
+        raise ValueError(f"mask shape {tuple(m.shape)} != {tuple(shape)}")
+    mm = m.to(device=device)
+    mm = (mm != 0) if mm.dtype != torch.bool else mm
+    mm = mm.contiguous().view(torch.uint8)
+    return mm, mm.data_ptr()
+
+
+# ------------------------------------------------------------------------------------------------
+# workspaces: one grow-only byte buffer per (device, stream); launches on a stream are ordered, so
+# consecutive blocks can share it.
+# ------------------------------------------------------------------------------------------------
+_workspaces: Dict[Tuple[int, int], torch.Tensor] = {}
+
+
+def workspace(device: torch.device, nbytes: int) -> torch.Tensor:
+    key = (device.index if device.index is not None else torch.cuda.current_device(), stream_ptr(device))
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = None
+        _workspaces.pop(key, None)
+        ws = torch.empty(int(nbytes * 1.05) + 4096, dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+def release_workspaces() -> None:
+    _workspaces.clear()
+
+
+# ------------------------------------------------------------------------------------------------
+# packed weights
+# ------------------------------------------------------------------------------------------------
+class PackedLinear:
+    """Device image of one nn.Linear in kernel layout (hi [+ lo] + padded bias) and its descriptor."""
+
+    def __init__(self, weight: torch.Tensor, bias: Optional[torch.Tensor], row_heads: int, col_heads: int,
+                 dtype: int, two_pass: bool):
+        require_device(weight, "pack_linear")
+        lib = L.lib()
+        out, inn = weight.shape
+        if out % row_heads or inn % col_heads:
+            raise ValueError("channels must be divisible by the head count")
+        self.n = row_heads * pad8(out // row_heads)
+        self.k = col_heads * pad8(inn // col_heads)
+        dev = weight.device
+        w = weight.detach()
+        if w.dtype != torch.float32 or not w.is_contiguous():
+            w = w.float().contiguous()
+        tdt = torch.float16 if dtype == L.PIO_DT_F16 else torch.bfloat16
+        self.hi = torch.empty((self.n, self.k), dtype=tdt, device=dev)
+        self.lo = torch.empty((self.n, self.k), dtype=tdt, device=dev) if two_pass else None
+        self.bias = torch.empty((self.n,), dtype=torch.float32, device=dev)
+        b = None
+        if bias is not None:
+            b = bias.detach()
+            if b.dtype != torch.float32 or not b.is_contiguous():
+                b = b.float().contiguous()
+        L.check(lib.pio_pack_linear(w.data_ptr(), b.data_ptr() if b is not None else None, out, inn, inn,
+                                    row_heads, col_heads, self.hi.data_ptr(),
+                                    self.lo.data_ptr() if two_pass else None, self.bias.data_ptr(), 0, self.k,
+                                    dtype, stream_ptr(dev)), "pio_pack_linear")
+        self.desc = L.Linear(self.hi.data_ptr(), self.lo.data_ptr() if two_pass else None, self.bias.data_ptr(),
+                             self.n, self.k)
+
+
+def param_key(*params) -> tuple:
+    """Cache key that changes whenever a parameter is rebound, moved or modified in place."""
+    return tuple((p.data_ptr(), p._version, str(p.device)) if p is not None else None for p in params) + (_policy,)
+
+
+def layernorm_desc(ln: torch.nn.LayerNorm, keep: list) -> L.LayerNorm:
+    w, b = ln.weight.detach(), ln.bias.detach()
+    if w.dtype != torch.float32:
+        w, b = w.float(), b.float()
+    w, b = w.contiguous(), b.contiguous()
+    keep += [w, b]
+    return L.LayerNorm(w.data_ptr(), b.data_ptr(), w.numel(), float(ln.eps))

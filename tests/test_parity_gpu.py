@@ -1,0 +1,344 @@
+"""GPU parity tests proper: every call goes through the C-ABI of libpio_hip.so (via the nn.Module mirror or
+raw ctypes) and is compared with the committed reference goldens and with the oracle on the same seeded
+inputs.  Tolerance: 1e-3 on BOTH relL2 and max-abs/abs-max (BASELINE.json north_star), written here."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+import perceiver_oracle as O
+from cases import ENCDEC_CASES, gen_encdec_inputs, encdec_kwargs
+from _golden import load, params, ATTN, MLP, SA, CA, ENCDEC_FULL, ENCDEC_SUB
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-3          # the parity bar of north_star
+POLICIES = ["fp16x2w", "fp16"]
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    import perceiverio_pytorch_amd as P
+    assert P.lib().pio_arch_ok() == 1, "libpio_hip.so targets gfx950 only"
+    return torch.device("cuda:0")
+
+
+def _policy(name):
+    import perceiverio_pytorch_amd as P
+    P.set_precision_policy(name)
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _sd(p, dev):
+    return {k: _t(v, dev) for k, v in p.items()}
+
+
+def _errs(y, ref):
+    return O.rel_errors(y.detach().float().cpu().numpy(), ref)
+
+
+def _assert_close(y, ref, tol=TOL, what=""):
+    rl2, rmax = _errs(y, ref)
+    assert rl2 <= tol and rmax <= tol, f"{what}: relL2={rl2:.3e} max/absmax={rmax:.3e} > {tol}"
+    return rl2, rmax
+
+
+# ----------------------------------------------------------------------------------------------------
+# primitive kernels through raw ctypes
+# ----------------------------------------------------------------------------------------------------
+GEMM_SHAPES = [
+    # M, N, K, batch, nh, bias_mode, act, residual, out_f32, lo
+    (128, 128, 64, 1, 1, 0, 0, False, True, False),
+    (200, 136, 72, 1, 1, 1, 0, False, True, False),       # tails in M, N and K (K % 64 != 0)
+    (333, 1000, 1024, 1, 1, 1, 1, True, True, False),     # gelu + residual, fp32 out, ldc=1000
+    (77, 48, 328, 6, 3, 2, 0, False, False, False),       # batched (b,h), per-row bias, 16-bit out
+    (512, 512, 128, 4, 2, 0, 0, False, True, False),
+    (300, 264, 1024, 1, 1, 1, 0, True, True, True),       # two-pass weights
+    (1, 8, 8, 1, 1, 1, 0, False, True, False),            # degenerate
+]
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("shape", GEMM_SHAPES)
+def test_gemm_nt(dev, shape, dt):
+    from perceiverio_pytorch_amd import _lib as L
+    lib = L.lib()
+    M, N, K, batch, nh, bias_mode, act, resid, out_f32, lo = shape
+    tdt = torch.float16 if dt == "f16" else torch.bfloat16
+    g = torch.Generator(device="cpu").manual_seed(M * 7 + N)
+    A = torch.randn(batch, M, K, generator=g).to(tdt)
+    Bm = (torch.randn(batch, N, K, generator=g) / K ** 0.5)
+    Bhi = Bm.to(tdt)
+    Blo = (Bm - Bhi.float()).to(tdt)
+    bias = torch.randn(N if bias_mode == 1 else M, generator=g)
+    Rm = torch.randn(batch, M, N, generator=g)
+    ldc = N if out_f32 else (N + 7) // 8 * 8
+    Cout = torch.full((batch, M, ldc), float("nan"), dtype=torch.float32 if out_f32 else tdt)
+    Ad, Bd, Bld, bd, Rd, Cd = (x.to(dev) for x in (A, Bhi, Blo, bias, Rm, Cout))
+    gm = L.Gemm()
+    gm.A, gm.B, gm.C = Ad.data_ptr(), Bd.data_ptr(), Cd.data_ptr()
+    gm.B_lo = Bld.data_ptr() if lo else None
+    gm.M, gm.N, gm.K = M, N, K
+    gm.lda, gm.ldb, gm.ldc = K, K, ldc
+    gm.batch, gm.nh = batch, nh
+    # z = zb*nh + zh over a [batch] array: stride_b = nh matrices, stride_h = 1 matrix
+    gm.sAb, gm.sAh = nh * M * K, M * K
+    gm.sBb, gm.sBh = nh * N * K, N * K
+    gm.sCb, gm.sCh = nh * M * ldc, M * ldc
+    gm.bias = bd.data_ptr() if bias_mode else None
+    gm.bias_mode, gm.act, gm.alpha = bias_mode, act, 0.5
+    if resid:
+        assert batch == 1
+        gm.R, gm.ldr = Rd.data_ptr(), N
+    gm.out_f32, gm.n_store = int(out_f32), ldc
+    gm.dtype = L.PIO_DT_F16 if dt == "f16" else L.PIO_DT_BF16
+    L.check(lib.pio_gemm_nt(C.byref(gm), torch.cuda.current_stream().cuda_stream), "pio_gemm_nt")
+    torch.cuda.synchronize()
+    W = Bhi.double() + (Blo.double() if lo else 0)
+    ref = 0.5 * torch.einsum("bmk,bnk->bmn", A.double(), W)
+    if bias_mode == 1:
+        ref = ref + bias.double()[None, None, :]
+    elif bias_mode == 2:
+        ref = ref + bias.double()[None, :, None]
+    if act:
+        ref = torch.nn.functional.gelu(ref)
+    if resid:
+        ref = ref + Rm.double()
+    got = Cd.float().cpu().double()
+    assert torch.isfinite(got[:, :, :N]).all()
+    if not out_f32:
+        assert (got[:, :, N:] == 0).all(), "pad columns must be written as zeros"
+    tol = 2e-5 if out_f32 else (1e-3 if dt == "f16" else 8e-3)
+    err = (got[:, :, :N] - ref).abs().max() / ref.abs().max()
+    assert err <= tol, f"gemm {shape} {dt}: {err:.3e}"
+
+
+@pytest.mark.parametrize("C_", [322, 1024, 261, 8, 1280])
+@pytest.mark.parametrize("norm", [True, False])
+def test_layernorm_cast(dev, C_, norm):
+    from perceiverio_pytorch_amd import _lib as L, runtime as R
+    lib = L.lib()
+    B, T = 3, 37
+    g = torch.Generator().manual_seed(C_)
+    x = torch.randn(B, T, C_, generator=g) * 3 + 0.5
+    gamma = 1 + 0.1 * torch.randn(C_, generator=g)
+    beta = 0.1 * torch.randn(C_, generator=g)
+    cp = R.pad8(C_)
+    xd, gd, bd = x.to(dev), gamma.to(dev), beta.to(dev)
+    y = torch.full((B * T, cp), float("nan"), dtype=torch.float16, device=dev)
+    ln = L.LayerNorm(gd.data_ptr(), bd.data_ptr(), C_, 1e-5)
+    L.check(lib.pio_layernorm_cast(R.tensor3(xd), C.byref(ln) if norm else None, y.data_ptr(), cp, L.PIO_DT_F16,
+                                   torch.cuda.current_stream().cuda_stream), "pio_layernorm_cast")
+    ref = O.layer_norm(x.numpy().astype(np.float64), gamma.numpy().astype(np.float64),
+                       beta.numpy().astype(np.float64)) if norm else x.numpy().astype(np.float64)
+    got = y.float().cpu().numpy().reshape(B, T, cp)
+    assert (got[..., C_:] == 0).all()
+    assert np.abs(got[..., :C_] - ref).max() <= 1e-3 * np.abs(ref).max()      # fp16 rounding of the output
+    # broadcast (stride-0) batch view
+    xb = torch.broadcast_to(xd[0:1], (4, T, C_))
+    y2 = torch.empty((4 * T, cp), dtype=torch.float16, device=dev)
+    L.check(lib.pio_layernorm_cast(R.tensor3(xb), C.byref(ln) if norm else None, y2.data_ptr(), cp, L.PIO_DT_F16,
+                                   torch.cuda.current_stream().cuda_stream), "pio_layernorm_cast")
+    assert torch.equal(y2.view(4, T, cp)[3], y.view(B, T, cp)[0])
+
+
+@pytest.mark.parametrize("Tk", [13, 512, 3136, 5000])
+def test_softmax_rows(dev, Tk):
+    from perceiverio_pytorch_amd import _lib as L, runtime as R
+    lib = L.lib()
+    B, H, Tq = 2, 3, 9
+    g = torch.Generator().manual_seed(Tk)
+    S = torch.randn(B, H, Tq, Tk, generator=g) * 4
+    km = torch.rand(B, Tk, generator=g) > 0.3
+    km[1, :] = False if Tk == 13 else km[1, :]
+    qm = torch.rand(B, Tq, generator=g) > 0.3
+    tkp = R.pad8(Tk)
+    Sd = S.to(dev)
+    P = torch.full((B, H, Tq, tkp), float("nan"), dtype=torch.float16, device=dev)
+    kmd, qmd = km.to(dev).view(torch.uint8), qm.to(dev).view(torch.uint8)
+    scale = 0.37
+    L.check(lib.pio_softmax_rows(Sd.data_ptr(), Tk, P.data_ptr(), tkp, B, H, Tq, Tk, scale, kmd.data_ptr(),
+                                 qmd.data_ptr(), None, None, L.PIO_DT_F16, torch.cuda.current_stream().cuda_stream),
+            "pio_softmax_rows")
+    mask = O.make_cross_attention_mask(qm.numpy(), km.numpy())
+    s = S.numpy().astype(np.float64) * scale
+    s = np.where(mask[:, None], s, -1e30)
+    ref = O.softmax_lastdim(s)
+    ref = np.where(np.all(mask == 0, axis=2, keepdims=True)[:, None], 0.0, ref)
+    got = P.float().cpu().numpy()
+    assert (got[..., Tk:] == 0).all()
+    assert np.abs(got[..., :Tk] - ref).max() <= 1e-3 * max(ref.max(), 1e-9)
+
+
+# ----------------------------------------------------------------------------------------------------
+# module-level goldens (reference float32 outputs) through the nn.Module mirror
+# ----------------------------------------------------------------------------------------------------
+def _mask3(g, dev):
+    if "query_mask" in g:
+        return _t(O.make_cross_attention_mask(g["query_mask"], g["kv_mask"]), dev)
+    return None
+
+
+@pytest.mark.parametrize("policy", POLICIES)
+@pytest.mark.parametrize("name", ATTN)
+def test_attention_golden(dev, name, policy):
+    from perceiverio_pytorch_amd.transformer_primitives import Attention
+    _policy(policy)
+    g = load(name)
+    B, Tq, Tk, q_in, kv_in, H, qk, v, out = (int(x) for x in g["meta"])
+    m = Attention(q_in, kv_in, kv_in, num_heads=H, qk_out_channels=qk, v_out_channels=v, output_channels=out)
+    m.load_state_dict(_sd(params(g), "cpu"), strict=True)
+    m = m.to(dev).eval()
+    xq, xkv = _t(g["xq"], dev), _t(g["xkv"], dev)
+    with torch.inference_mode():
+        y = m(xq, xkv, xkv, attention_mask=_mask3(g, dev))
+    _assert_close(y, g["out"], what=name)
+
+
+def test_attention_wiped_rows_equal_final_bias(dev):
+    from perceiverio_pytorch_amd.transformer_primitives import Attention
+    _policy("fp16x2w")
+    g = load("attn_h4_fullmask_row")
+    B, Tq, Tk, q_in, kv_in, H, qk, v, out = (int(x) for x in g["meta"])
+    m = Attention(q_in, kv_in, kv_in, num_heads=H, qk_out_channels=qk, v_out_channels=v, output_channels=out)
+    m.load_state_dict(_sd(params(g), "cpu"))
+    m = m.to(dev).eval()
+    xq, xkv = _t(g["xq"], dev), _t(g["xkv"], dev)
+    y = m(xq, xkv, xkv, attention_mask=_mask3(g, dev))
+    fb = m.final.bias.detach()
+    assert torch.equal(y[1], fb[None, :].expand_as(y[1])), "fully masked sample must give final.bias exactly"
+
+
+def test_attention_return_matrix_and_bias(dev):
+    from perceiverio_pytorch_amd.transformer_primitives import Attention
+    _policy("fp16x2w")
+    g = load("attn_h8_keymask")
+    B, Tq, Tk, q_in, kv_in, H, qk, v, out = (int(x) for x in g["meta"])
+    p = params(g)
+    m = Attention(q_in, kv_in, kv_in, num_heads=H, qk_out_channels=qk, v_out_channels=v, output_channels=out)
+    m.load_state_dict(_sd(p, "cpu"))
+    m = m.to(dev).eval()
+    rng = np.random.default_rng(5)
+    bias = rng.standard_normal((B, H, Tq, Tk)).astype(np.float32)
+    mask = O.make_cross_attention_mask(g["query_mask"], g["kv_mask"])
+    pm, y = m(_t(g["xq"], dev), _t(g["xkv"], dev), _t(g["xkv"], dev), attention_mask=_t(mask, dev),
+              attention_bias=_t(bias, dev), return_matrix=True)
+    p64 = {k: a.astype(np.float64) for k, a in p.items()}
+    rm, ry = O.attention(p64, g["xq"].astype(np.float64), g["xkv"].astype(np.float64), g["xkv"].astype(np.float64),
+                         H, mask, bias.astype(np.float64), return_matrix=True)
+    _assert_close(y, ry, what="attention with bias")
+    assert np.abs(pm.cpu().numpy() - rm).max() <= 2e-3
+
+
+@pytest.mark.parametrize("policy", POLICIES)
+@pytest.mark.parametrize("name", MLP)
+def test_mlp_golden(dev, name, policy):
+    from perceiverio_pytorch_amd.transformer_primitives import MLP as HipMLP
+    _policy(policy)
+    g = load(name)
+    cin, w = (int(x) for x in g["meta"])
+    m = HipMLP(cin, widening_factor=w)
+    m.load_state_dict(_sd(params(g), "cpu"), strict=True)
+    m = m.to(dev).eval()
+    _assert_close(m(_t(g["x"], dev)), g["out"], what=name)
+
+
+@pytest.mark.parametrize("policy", POLICIES)
+@pytest.mark.parametrize("name", SA)
+def test_self_attention_golden(dev, name, policy):
+    from perceiverio_pytorch_amd.transformer_primitives import SelfAttention
+    _policy(policy)
+    g = load(name)
+    B, N, D, H, w = (int(x) for x in g["meta"])
+    m = SelfAttention(D, widening_factor=w, num_heads=H)
+    m.load_state_dict(_sd(params(g), "cpu"), strict=True)
+    m = m.to(dev).eval()
+    _assert_close(m(_t(g["x"], dev)), g["out"], what=name)
+
+
+@pytest.mark.parametrize("policy", POLICIES)
+@pytest.mark.parametrize("name", CA)
+def test_cross_attention_golden(dev, name, policy):
+    from perceiverio_pytorch_amd.transformer_primitives import CrossAttention
+    _policy(policy)
+    g = load(name)
+    B, Tq, Tk, q_in, kv_in, H, resid, kv = (int(x) for x in g["meta"])
+    m = CrossAttention(q_in, kv_in, num_heads=H, shape_for_attn="kv" if kv else "q", use_query_residual=bool(resid))
+    m.load_state_dict(_sd(params(g), "cpu"), strict=True)
+    m = m.to(dev).eval()
+    y = m(_t(g["xq"], dev), _t(g["xkv"], dev), attention_mask=_mask3(g, dev))
+    _assert_close(y, g["out"], what=name)
+
+
+def build_encdec(cfg, p_enc, p_dec, dev):
+    from perceiverio_pytorch_amd.perceiver import PerceiverEncoder, PerceiverDecoder
+    enc = PerceiverEncoder(num_input_channels=cfg["C"], num_self_attends_per_block=cfg["L"], num_blocks=cfg["blocks"],
+                           num_latents=cfg["N"], num_latent_channels=cfg["D"], qk_channels=cfg.get("qk"),
+                           v_channels=cfg.get("v"), num_cross_attend_heads=cfg["xh"],
+                           num_self_attend_heads=cfg["sh"], use_query_residual=cfg["enc_resid"])
+    dec = PerceiverDecoder(query_channels=cfg["Dq"], final_project_out_channels=cfg["out"] or cfg["Dq"],
+                           num_latent_channels=cfg["D"], qk_channels=cfg.get("dqk"), v_channels=cfg.get("dv"),
+                           use_query_residual=cfg["dec_resid"], num_heads=cfg["dh"],
+                           final_project=cfg["out"] is not None)
+    enc.load_state_dict(_sd(p_enc, "cpu"), strict=True)
+    dec.load_state_dict(_sd(p_dec, "cpu"), strict=True)
+    return enc.to(dev).eval(), dec.to(dev).eval()
+
+
+def run_encdec(enc, dec, x, qtab, im, qm, dev):
+    with torch.inference_mode():
+        xt = _t(x, dev)
+        z = enc(xt, enc.latents(xt), input_mask=None if im is None else _t(im, dev))
+        q = torch.broadcast_to(_t(qtab, dev)[None], (x.shape[0],) + qtab.shape)
+        y = dec(q, z, query_mask=None if qm is None else _t(qm, dev))
+    return z, y
+
+
+@pytest.mark.parametrize("policy", POLICIES)
+@pytest.mark.parametrize("name", ENCDEC_FULL)
+def test_encdec_full_golden(dev, name, policy):
+    _policy(policy)
+    g = load(name)
+    cfg = ENCDEC_CASES[name]
+    enc, dec = build_encdec(cfg, params(g, "enc."), params(g, "dec."), dev)
+    z, y = run_encdec(enc, dec, g["x"], g["qtab"], g.get("input_mask"), g.get("query_mask"), dev)
+    _assert_close(z, g["latents"], what=name + " latents")
+    _assert_close(y, g["out"], what=name)
+
+
+@pytest.mark.parametrize("policy", POLICIES)
+@pytest.mark.parametrize("name", ENCDEC_SUB + ["encdec_imagenet_b2"])
+def test_encdec_subsampled_golden(dev, name, policy):
+    _policy(policy)
+    g = load(name)
+    cfg = ENCDEC_CASES[name]
+    p_enc, p_dec, qtab, x, im, qm = gen_encdec_inputs(name, cfg, int(g["seed"]))
+    enc, dec = build_encdec(cfg, p_enc, p_dec, dev)
+    z, y = run_encdec(enc, dec, x, qtab, im, qm, dev)
+    ysub = y[:, torch.from_numpy(g["out_rows"]).to(dev), :]
+    # error relative to the WHOLE output's magnitude (stored with the golden), reference = float32 run
+    d = ysub.cpu().numpy().astype(np.float64) - g["out"].astype(np.float64)
+    rmax = np.abs(d).max() / float(g["out_absmax"])
+    rl2 = np.sqrt((d * d).sum()) / np.sqrt((g["out"].astype(np.float64) ** 2).sum())
+    print(f"{name} [{policy}] relL2={rl2:.3e} max/absmax={rmax:.3e}")
+    assert rl2 <= TOL and rmax <= TOL, f"{name} [{policy}]: relL2={rl2:.3e} max/absmax={rmax:.3e}"
+    _assert_close(z[:, ::8, ::8], g["latents_sub"], what=name + " latents")
+
+
+def test_oracle_same_inputs_mid(dev):
+    """HIP path vs the oracle (float64) on the same seeded inputs, a shape with awkward tails."""
+    _policy("fp16x2w")
+    cfg = dict(B=3, M=203, C=45, N=37, D=72, L=2, blocks=2, xh=1, sh=4, enc_resid=True, Q=19, Dq=40, out=11, dh=1,
+               dec_resid=False, masks=True)
+    p_enc, p_dec, qtab, x, im, qm = gen_encdec_inputs("tails", cfg, 5)
+    enc, dec = build_encdec(cfg, p_enc, p_dec, dev)
+    z, y = run_encdec(enc, dec, x, qtab, im, qm, dev)
+    c64 = lambda d: {k: a.astype(np.float64) for k, a in d.items()}  # noqa: E731
+    ref = O.encode_decode(c64(p_enc), c64(p_dec), x.astype(np.float64), qtab.astype(np.float64),
+                          **encdec_kwargs(cfg, im, qm))
+    _assert_close(y, ref, what="tails")
