@@ -74,7 +74,8 @@ typedef struct pio_attention_t {
     int32_t dk, dv;   /* logical channels per head for q/k and v  */
     int32_t dkp, dvp; /* padded (multiple of 8)                    */
     int32_t q_in, k_in, v_in, out; /* logical channel counts (k_in == v_in inside Self/CrossAttention) */
-    int32_t dtype;    /* PIO_DT_*                                  */
+    int32_t dtype;     /* PIO_DT_*                                  */
+    int32_t act_split; /* 1: activations are carried as hi+lo pairs too (3 MFMA sweeps, ~fp32 products) */
 } pio_attention_t;
 
 /* MLP (transformer_primitives.py:183-216) */
@@ -82,6 +83,7 @@ typedef struct pio_mlp_t {
     pio_linear_t fc1, fc2;
     int32_t in, hidden, out;
     int32_t dtype;
+    int32_t act_split;
 } pio_mlp_t;
 
 /* SelfAttention (transformer_primitives.py:219-297) */
@@ -129,8 +131,9 @@ int pio_pack_linear(const float *w, const float *bias, int32_t out, int32_t in, 
 
 /* --- primitive kernels (exposed for tests and for callers that compose their own blocks) ------- */
 /* y[r, 0:c_pad] = operand_dtype( LN(x[r, 0:c]) ) with zero fill of [c, c_pad); ln == NULL => plain
- * cast.  Rows are (b, t) of x.  Replaces nn.LayerNorm + the implicit cast in front of every GEMM. */
-int pio_layernorm_cast(const pio_tensor3_t *x, const pio_layernorm_t *ln, void *y, int32_t c_pad,
+ * cast.  Rows are (b, t) of x.  y_lo (optional) receives the rounding residual v - float(y).
+ * Replaces nn.LayerNorm + the implicit cast in front of every GEMM. */
+int pio_layernorm_cast(const pio_tensor3_t *x, const pio_layernorm_t *ln, void *y, void *y_lo, int32_t c_pad,
                        int32_t dtype, void *stream);
 
 /* C = epilogue(alpha * A B^T): A [M,K], B [N,K] operand dtype, K contiguous (multiple of 8).
@@ -141,8 +144,9 @@ int pio_layernorm_cast(const pio_tensor3_t *x, const pio_layernorm_t *ln, void *
  * output fp32 (out_f32=1) or operand dtype with zero fill of columns [N, n_store). */
 typedef struct pio_gemm_t {
     const void *A, *B;
-    const void *A_lo, *B_lo; /* optional second pass: C += A_lo*B^T resp. A*B_lo^T (two-pass weights) */
+    const void *A_lo, *B_lo; /* optional extra K sweeps: C += A*B_lo^T, C += A_lo*B^T (split operands) */
     void *C;
+    void *C_lo;              /* optional (16-bit output only): residual C - float(C16), same layout as C */
     int32_t M, N, K;
     int64_t lda, ldb, ldc;
     int32_t batch, nh;
@@ -163,9 +167,9 @@ int pio_gemm_nt(const pio_gemm_t *g, void *stream);
 /* P = softmax_j((S + bias) * scale) with masking, rows of length Tk (transformer_primitives.py:143-158,
  * 168-175): S fp32 [B,H,Tq,Tk] (row stride lds), P operand dtype [B,H,Tq,ldp] zero filled to ldp.
  * kv_mask [B,Tk], q_mask [B,Tq], full_mask [B,Tq,Tk] are optional uint8.  A row with no attendable key
- * is written as zeros (the reference's "wipe").  bias optional fp32 [B,H,Tq,Tk]. */
-int pio_softmax_rows(const float *S, int64_t lds, void *P, int64_t ldp, int32_t B, int32_t H, int32_t Tq,
-                     int32_t Tk, float scale, const uint8_t *kv_mask, const uint8_t *q_mask,
+ * is written as zeros (the reference's "wipe").  bias optional fp32 [B,H,Tq,Tk]; P_lo optional residual. */
+int pio_softmax_rows(const float *S, int64_t lds, void *P, void *P_lo, int64_t ldp, int32_t B, int32_t H,
+                     int32_t Tq, int32_t Tk, float scale, const uint8_t *kv_mask, const uint8_t *q_mask,
                      const uint8_t *full_mask, const float *bias, int32_t dtype, void *stream);
 
 /* --- blocks: the reference's nn.Module.forward calls ------------------------------------------ */

@@ -37,12 +37,13 @@ class LayerNorm(C.Structure):
 class Attention(C.Structure):
     _fields_ = [("q", Linear), ("k", Linear), ("v", Linear), ("o", Linear), ("heads", C.c_int32),
                 ("dk", C.c_int32), ("dv", C.c_int32), ("dkp", C.c_int32), ("dvp", C.c_int32),
-                ("q_in", C.c_int32), ("k_in", C.c_int32), ("v_in", C.c_int32), ("out", C.c_int32), ("dtype", C.c_int32)]
+                ("q_in", C.c_int32), ("k_in", C.c_int32), ("v_in", C.c_int32), ("out", C.c_int32), ("dtype", C.c_int32),
+                ("act_split", C.c_int32)]
 
 
 class Mlp(C.Structure):
     _fields_ = [("fc1", Linear), ("fc2", Linear), ("in_", C.c_int32), ("hidden", C.c_int32), ("out", C.c_int32),
-                ("dtype", C.c_int32)]
+                ("dtype", C.c_int32), ("act_split", C.c_int32)]
 
 
 class SelfAttention(C.Structure):
@@ -61,6 +62,7 @@ class Tensor3(C.Structure):
 
 class Gemm(C.Structure):
     _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("A_lo", C.c_void_p), ("B_lo", C.c_void_p), ("C", C.c_void_p),
+                ("C_lo", C.c_void_p),
                 ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
                 ("lda", C.c_int64), ("ldb", C.c_int64), ("ldc", C.c_int64),
                 ("batch", C.c_int32), ("nh", C.c_int32),
@@ -83,9 +85,9 @@ SIGNATURES = {
     "pio_pad8": (_i32, [_i32]),
     "pio_packed_weight_bytes": (_sz, [_i32, _i32, _i32, _i32]),
     "pio_pack_linear": (C.c_int, [_vp, _vp, _i32, _i32, _i64, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
-    "pio_layernorm_cast": (C.c_int, [P(Tensor3), P(LayerNorm), _vp, _i32, _i32, _vp]),
+    "pio_layernorm_cast": (C.c_int, [P(Tensor3), P(LayerNorm), _vp, _vp, _i32, _i32, _vp]),
     "pio_gemm_nt": (C.c_int, [P(Gemm), _vp]),
-    "pio_softmax_rows": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _f, _vp, _vp, _vp, _vp, _i32, _vp]),
+    "pio_softmax_rows": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _f, _vp, _vp, _vp, _vp, _i32, _vp]),
     "pio_attention_workspace_bytes": (_sz, [P(Attention), _i32, _i32, _i32]),
     "pio_attention_fwd": (C.c_int, [P(Attention), P(Tensor3), P(Tensor3), P(Tensor3), _vp, _vp, _vp, _vp, _vp, _vp,
                                     _vp, _sz, _vp]),

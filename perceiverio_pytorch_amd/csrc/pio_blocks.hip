@@ -7,6 +7,9 @@
 //   self_attention   <- SelfAttention.forward              transformer_primitives.py:275-297
 //   cross_attention  <- CrossAttention.forward             transformer_primitives.py:371-406
 //   encoder / decoder<- PerceiverEncoder/Decoder.forward   perceiver.py:98-107, 166-180
+//
+// 16-bit operands travel as (hi, lo) pairs: lo == nullptr unless the descriptor says act_split
+// (precision policy "*x3": every product is hi*hi + hi*lo + lo*hi, i.e. ~fp32-exact).
 #include "pio_internal.h"
 
 namespace pio {
@@ -16,6 +19,17 @@ namespace pio {
         int _e = (expr);               \
         if (_e != PIO_OK) return _e;   \
     } while (0)
+
+struct Pair {  // a 16-bit operand and its optional rounding residual
+    void *hi = nullptr, *lo = nullptr;
+};
+
+static Pair take_pair(Carver &c, size_t elems, bool split) {
+    Pair p;
+    p.hi = c.take(elems * 2);
+    p.lo = split ? c.take(elems * 2) : nullptr;
+    return p;
+}
 
 struct Residual {
     const float *ptr = nullptr;
@@ -41,14 +55,16 @@ static pio_gemm_t gemm_defaults(int dtype) {
     return g;
 }
 
-// y[rows, n] = x16[rows, lin.k] * W^T (+bias) (act) (+R); 16-bit output has ldc = lin.n (padded).
-static int linear_fwd(const pio_linear_t &lin, int dtype, const void *x16, int64_t rows, void *y, bool out_f32,
+// y[rows, n] = x16[rows, lin.k] * W^T (+bias) (act) (+R); a 16-bit output has ldc = lin.n (padded).
+static int linear_fwd(const pio_linear_t &lin, int dtype, Pair x, int64_t rows, void *y, void *y_lo, bool out_f32,
                       int n_logical, int64_t ldc, int act, const Residual *res, hipStream_t s) {
     pio_gemm_t g = gemm_defaults(dtype);
-    g.A = x16;
+    g.A = x.hi;
+    g.A_lo = x.lo;
     g.B = lin.w_hi;
     g.B_lo = lin.w_lo;
     g.C = y;
+    g.C_lo = y_lo;
     g.M = (int)rows;
     g.N = out_f32 ? n_logical : lin.n;
     g.K = lin.k;
@@ -69,20 +85,25 @@ static int linear_fwd(const pio_linear_t &lin, int dtype, const void *x16, int64
     return gemm_nt_launch(g, s);
 }
 
+static int cast_pair(const pio_tensor3_t &x, const pio_layernorm_t *ln, Pair y, int c_pad, int dtype, hipStream_t s) {
+    return layernorm_cast_launch(x, ln, y.hi, y.lo, c_pad, dtype, s);
+}
+
 // ------------------------------------------------------------------------------------------------------
 // attention core on already normalised / cast 16-bit inputs
 // ------------------------------------------------------------------------------------------------------
 struct AttnScratch {
-    void *q16, *k16, *vt16, *p16, *o16;
+    Pair q16, k16, vt16, p16, o16;
     float *scores;
     void carve(Carver &c, const pio_attention_t &a, int Bq, int B, int Tq, int Tk) {
         const int64_t ldq = (int64_t)a.heads * a.dkp, ldo = (int64_t)a.heads * a.dvp, tkp = pad8(Tk);
-        q16 = c.take((size_t)Bq * Tq * ldq * 2);
-        k16 = c.take((size_t)B * Tk * ldq * 2);
-        vt16 = c.take((size_t)B * ldo * tkp * 2);
+        const bool sp = a.act_split != 0;
+        q16 = take_pair(c, (size_t)Bq * Tq * ldq, sp);
+        k16 = take_pair(c, (size_t)B * Tk * ldq, sp);
+        vt16 = take_pair(c, (size_t)B * ldo * tkp, sp);
         scores = (float *)c.take((size_t)B * a.heads * Tq * (int64_t)Tk * 4);
-        p16 = c.take((size_t)B * a.heads * Tq * tkp * 2);
-        o16 = c.take((size_t)B * Tq * ldo * 2);
+        p16 = take_pair(c, (size_t)B * a.heads * Tq * tkp, sp);
+        o16 = take_pair(c, (size_t)B * Tq * ldo, sp);
     }
 };
 
@@ -93,21 +114,22 @@ static int check_attention(const pio_attention_t &a) {
     if (a.o.k != a.heads * a.dvp || a.q.k != pad8(a.q_in) || a.k.k != pad8(a.k_in) || a.v.k != pad8(a.v_in))
         return PIO_E_SHAPE;
     if (!a.q.w_hi || !a.k.w_hi || !a.v.w_hi || !a.o.w_hi) return PIO_E_ARG;
+    if (a.act_split && (!a.q.w_lo || !a.k.w_lo || !a.v.w_lo || !a.o.w_lo)) return PIO_E_ARG;
     return PIO_OK;
 }
 
-static int attention_core(const pio_attention_t &a, const void *xq16, bool q_bcast, const void *xk16,
-                          const void *xv16, int B, int Tq, int Tk, const uint8_t *kv_mask, const uint8_t *q_mask,
-                          const uint8_t *full_mask, const float *attention_bias, const Residual *res, float *out,
-                          float *probs_out, AttnScratch &w, hipStream_t s) {
+static int attention_core(const pio_attention_t &a, Pair xq, bool q_bcast, Pair xk, Pair xv, int B, int Tq, int Tk,
+                          const uint8_t *kv_mask, const uint8_t *q_mask, const uint8_t *full_mask,
+                          const float *attention_bias, const Residual *res, float *out, float *probs_out,
+                          AttnScratch &w, hipStream_t s) {
     PIO_TRY(check_attention(a));
     const int H = a.heads;
     const int64_t ldq = (int64_t)H * a.dkp, ldo = (int64_t)H * a.dvp, tkp = pad8(Tk);
     const int Bq = q_bcast ? 1 : B;
 
     // 1/2: Q and K projections (transformer_primitives.py:93-94), head-padded columns
-    PIO_TRY(linear_fwd(a.q, a.dtype, xq16, (int64_t)Bq * Tq, w.q16, false, 0, ldq, 0, nullptr, s));
-    PIO_TRY(linear_fwd(a.k, a.dtype, xk16, (int64_t)B * Tk, w.k16, false, 0, ldq, 0, nullptr, s));
+    PIO_TRY(linear_fwd(a.q, a.dtype, xq, (int64_t)Bq * Tq, w.q16.hi, w.q16.lo, false, 0, ldq, 0, nullptr, s));
+    PIO_TRY(linear_fwd(a.k, a.dtype, xk, (int64_t)B * Tk, w.k16.hi, w.k16.lo, false, 0, ldq, 0, nullptr, s));
 
     // 3: V^T[b] = Wv * X_v[b]^T + bv (transformer_primitives.py:95) produced directly in the K-contiguous layout
     //    the P*V product wants; the weight is the A operand (batch stride 0), bias is per output ROW.
@@ -115,8 +137,10 @@ static int attention_core(const pio_attention_t &a, const void *xq16, bool q_bca
         pio_gemm_t g = gemm_defaults(a.dtype);
         g.A = a.v.w_hi;
         g.A_lo = a.v.w_lo;
-        g.B = xv16;
-        g.C = w.vt16;
+        g.B = xv.hi;
+        g.B_lo = xv.lo;
+        g.C = w.vt16.hi;
+        g.C_lo = w.vt16.lo;
         g.M = a.v.n;
         g.N = Tk;
         g.K = a.v.k;
@@ -134,8 +158,10 @@ static int attention_core(const pio_attention_t &a, const void *xq16, bool q_bca
     // 4: S[b,h] = Q[b,h] K[b,h]^T (transformer_primitives.py:138), fp32 scores
     {
         pio_gemm_t g = gemm_defaults(a.dtype);
-        g.A = w.q16;
-        g.B = w.k16;
+        g.A = w.q16.hi;
+        g.A_lo = w.q16.lo;
+        g.B = w.k16.hi;
+        g.B_lo = w.k16.lo;
         g.C = w.scores;
         g.M = Tq;
         g.N = Tk;
@@ -156,14 +182,17 @@ static int attention_core(const pio_attention_t &a, const void *xq16, bool q_bca
         PIO_TRY(gemm_nt_launch(g, s));
     }
     // 5: bias, scale, mask, softmax, wipe (transformer_primitives.py:143-158, 168-175)
-    PIO_TRY(softmax_rows_launch(w.scores, Tk, w.p16, tkp, B, H, Tq, Tk, 1.0f / sqrtf((float)a.dk), kv_mask, q_mask,
-                                full_mask, attention_bias, a.dtype, probs_out, s));
+    PIO_TRY(softmax_rows_launch(w.scores, Tk, w.p16.hi, w.p16.lo, tkp, B, H, Tq, Tk, 1.0f / sqrtf((float)a.dk),
+                                kv_mask, q_mask, full_mask, attention_bias, a.dtype, probs_out, s));
     // 6: O[b,:,h] = P[b,h] V[b,h] (transformer_primitives.py:163-166), heads merged by the store layout
     {
         pio_gemm_t g = gemm_defaults(a.dtype);
-        g.A = w.p16;
-        g.B = w.vt16;
-        g.C = w.o16;
+        g.A = w.p16.hi;
+        g.A_lo = w.p16.lo;
+        g.B = w.vt16.hi;
+        g.B_lo = w.vt16.lo;
+        g.C = w.o16.hi;
+        g.C_lo = w.o16.lo;
         g.M = Tq;
         g.N = a.dvp;
         g.K = (int)tkp;
@@ -182,34 +211,33 @@ static int attention_core(const pio_attention_t &a, const void *xq16, bool q_bca
         PIO_TRY(gemm_nt_launch(g, s));
     }
     // 7: final projection (+ residual) (transformer_primitives.py:110; SelfAttention :290, CrossAttention :396-399)
-    return linear_fwd(a.o, a.dtype, w.o16, (int64_t)B * Tq, out, true, a.out, a.out, 0, res, s);
+    return linear_fwd(a.o, a.dtype, w.o16, (int64_t)B * Tq, out, nullptr, true, a.out, a.out, 0, res, s);
 }
 
 // ------------------------------------------------------------------------------------------------------
 // MLP core on a 16-bit input
 // ------------------------------------------------------------------------------------------------------
-static int mlp_core(const pio_mlp_t &m, const void *x16, int64_t rows, void *h16, const Residual *res, float *out,
+static int mlp_core(const pio_mlp_t &m, Pair x, int64_t rows, Pair h, const Residual *res, float *out,
                     hipStream_t s) {
     if (m.fc1.k != pad8(m.in) || m.fc1.n != pad8(m.hidden) || m.fc2.k != m.fc1.n) return PIO_E_SHAPE;
-    PIO_TRY(linear_fwd(m.fc1, m.dtype, x16, rows, h16, false, 0, m.fc1.n, 1, nullptr, s));
-    return linear_fwd(m.fc2, m.dtype, h16, rows, out, true, m.out, m.out, 0, res, s);
+    if (m.act_split && (!m.fc1.w_lo || !m.fc2.w_lo)) return PIO_E_ARG;
+    PIO_TRY(linear_fwd(m.fc1, m.dtype, x, rows, h.hi, h.lo, false, 0, m.fc1.n, 1, nullptr, s));
+    return linear_fwd(m.fc2, m.dtype, h, rows, out, nullptr, true, m.out, m.out, 0, res, s);
 }
 
 // ======================================================================================================
-// Attention.forward
+// plans (workspace layouts)
 // ======================================================================================================
 struct AttentionPlan {
-    void *xq16, *xk16, *xv16;
+    Pair xq16, xk16, xv16;
     AttnScratch core;
-    bool q_bcast, kv_same;
     size_t carve(void *base, const pio_attention_t &a, int B, int Tq, int Tk, bool qb, bool same) {
         Carver c(base);
-        q_bcast = qb;
-        kv_same = same;
+        const bool sp = a.act_split != 0;
         const int Bq = qb ? 1 : B;
-        xq16 = c.take((size_t)Bq * Tq * pad8(a.q_in) * 2);
-        xk16 = c.take((size_t)B * Tk * pad8(a.k_in) * 2);
-        xv16 = same ? xk16 : c.take((size_t)B * Tk * pad8(a.v_in) * 2);
+        xq16 = take_pair(c, (size_t)Bq * Tq * pad8(a.q_in), sp);
+        xk16 = take_pair(c, (size_t)B * Tk * pad8(a.k_in), sp);
+        xv16 = same ? xk16 : take_pair(c, (size_t)B * Tk * pad8(a.v_in), sp);
         core.carve(c, a, Bq, B, Tq, Tk);
         return c.off;
     }
@@ -225,6 +253,113 @@ static pio_tensor3_t first_batch(const pio_tensor3_t &t) {
     r.B = 1;
     return r;
 }
+
+static Pair pair_if(Pair p, bool split) {
+    if (!split) p.lo = nullptr;
+    return p;
+}
+
+struct SelfPlan {
+    Pair x16, h16;
+    float *x1;
+    AttnScratch core;
+    size_t carve(void *base, const pio_self_attention_t &sa, int B, int N) {
+        Carver c(base);
+        const int64_t rows = (int64_t)B * N;
+        const int cmax = pad8(sa.attn.q_in) > pad8(sa.mlp.in) ? pad8(sa.attn.q_in) : pad8(sa.mlp.in);
+        x16 = take_pair(c, (size_t)rows * cmax, sa.attn.act_split || sa.mlp.act_split);
+        h16 = take_pair(c, (size_t)rows * pad8(sa.mlp.hidden), sa.mlp.act_split != 0);
+        x1 = (float *)c.take((size_t)rows * sa.attn.out * 4);
+        core.carve(c, sa.attn, B, B, N, N);
+        return c.off;
+    }
+};
+
+static int self_attention_run(const pio_self_attention_t &sa, const pio_tensor3_t &x, const uint8_t *kv_mask,
+                              const uint8_t *q_mask, const uint8_t *full_mask, const float *attention_bias,
+                              float *out, float *probs_out, SelfPlan &p, hipStream_t s) {
+    const int B = x.B, N = x.T;
+    const int64_t rows = (int64_t)B * N;
+    if (x.C != sa.attn.q_in || sa.attn.k_in != x.C || sa.attn.v_in != x.C || sa.attn.out != x.C ||
+        sa.mlp.in != x.C || sa.mlp.out != x.C)
+        return PIO_E_SHAPE;  // residual adds need matching widths (the reference raises a RuntimeError)
+    // LN1 -> attention -> + x     (transformer_primitives.py:281-290)
+    const Pair xa = pair_if(p.x16, sa.attn.act_split);
+    PIO_TRY(cast_pair(x, &sa.ln1, xa, pad8(x.C), sa.attn.dtype, s));
+    const Residual rx = residual_of(x);
+    PIO_TRY(attention_core(sa.attn, xa, false, xa, xa, B, N, N, kv_mask, q_mask, full_mask, attention_bias, &rx, p.x1,
+                           probs_out, p.core, s));
+    // LN2 -> MLP -> + x1          (transformer_primitives.py:292)
+    pio_tensor3_t t1 = {p.x1, (int64_t)N * x.C, x.C, B, N, x.C};
+    const Pair xm = pair_if(p.x16, sa.mlp.act_split);
+    PIO_TRY(cast_pair(t1, &sa.ln2, xm, pad8(x.C), sa.mlp.dtype, s));
+    const Residual r1 = residual_of(t1);
+    return mlp_core(sa.mlp, xm, rows, p.h16, &r1, out, s);
+}
+
+struct CrossPlan {
+    Pair q16, kv16, h16;
+    float *x1;
+    AttnScratch core;
+    bool q_bcast;
+    size_t carve(void *base, const pio_cross_attention_t &ca, int B, int Tq, int Tk, bool qb) {
+        Carver c(base);
+        q_bcast = qb;
+        const int Bq = qb ? 1 : B;
+        const int64_t rows = (int64_t)B * Tq;
+        const bool sp = ca.attn.act_split || ca.mlp.act_split;
+        // q16 is reused for LN2(x1): size it for all B*Tq rows
+        q16 = take_pair(c, (size_t)rows * pad8(ca.attn.q_in), sp);
+        kv16 = take_pair(c, (size_t)B * Tk * pad8(ca.attn.k_in), ca.attn.act_split != 0);
+        h16 = take_pair(c, (size_t)rows * pad8(ca.mlp.hidden), ca.mlp.act_split != 0);
+        x1 = (float *)c.take((size_t)rows * ca.attn.out * 4);
+        core.carve(c, ca.attn, Bq, B, Tq, Tk);
+        return c.off;
+    }
+};
+
+static int cross_attention_run(const pio_cross_attention_t &ca, const pio_tensor3_t &iq, const pio_tensor3_t &ikv,
+                               const uint8_t *kv_mask, const uint8_t *q_mask, const uint8_t *full_mask,
+                               const float *attention_bias, float *out, float *probs_out, CrossPlan &p,
+                               hipStream_t s) {
+    const int B = iq.B, Tq = iq.T, Tk = ikv.T;
+    const int64_t rows = (int64_t)B * Tq;
+    if (iq.C != ca.attn.q_in || ikv.C != ca.attn.k_in || ikv.C != ca.attn.v_in || ikv.B != B) return PIO_E_SHAPE;
+    if (ca.attn.out != iq.C || ca.mlp.in != iq.C || ca.mlp.out != iq.C) return PIO_E_SHAPE;
+    // layer_norm_kv, layer_norm_q  (transformer_primitives.py:379-380)
+    PIO_TRY(cast_pair(ikv, &ca.ln_kv, p.kv16, pad8(ikv.C), ca.attn.dtype, s));
+    const pio_tensor3_t q1 = p.q_bcast ? first_batch(iq) : iq;
+    const Pair qa = pair_if(p.q16, ca.attn.act_split);
+    PIO_TRY(cast_pair(q1, &ca.ln_q, qa, pad8(iq.C), ca.attn.dtype, s));
+    const Residual rq = residual_of(iq);
+    PIO_TRY(attention_core(ca.attn, qa, p.q_bcast, p.kv16, p.kv16, B, Tq, Tk, kv_mask, q_mask, full_mask,
+                           attention_bias, ca.use_query_residual ? &rq : nullptr, p.x1, probs_out, p.core, s));
+    // x + MLP(LN2(x))  (transformer_primitives.py:401)
+    pio_tensor3_t t1 = {p.x1, (int64_t)Tq * iq.C, iq.C, B, Tq, iq.C};
+    const Pair qm = pair_if(p.q16, ca.mlp.act_split);
+    PIO_TRY(cast_pair(t1, &ca.ln2, qm, pad8(iq.C), ca.mlp.dtype, s));
+    const Residual r1 = residual_of(t1);
+    return mlp_core(ca.mlp, qm, rows, p.h16, &r1, out, s);
+}
+
+struct DecoderPlan {
+    CrossPlan cp;
+    float *y;
+    Pair y16;
+    size_t carve(void *base, const pio_cross_attention_t &cross, const pio_linear_t *fin, int B, int Q, int N,
+                 bool qb) {
+        Carver c(base);
+        const int64_t rows = (int64_t)B * Q;
+        y = nullptr;
+        y16 = Pair();
+        if (fin) {
+            y = (float *)c.take((size_t)rows * cross.attn.q_in * 4);
+            y16 = take_pair(c, (size_t)rows * pad8(cross.attn.q_in), cross.mlp.act_split != 0);
+        }
+        const size_t inner = cp.carve(base ? (char *)base + c.off : nullptr, cross, B, Q, N, qb);
+        return c.off + inner;
+    }
+};
 
 }  // namespace pio
 
@@ -252,9 +387,9 @@ int pio_attention_fwd(const pio_attention_t *a, const pio_tensor3_t *iq, const p
     AttentionPlan p;
     if (p.carve(workspace, *a, B, Tq, Tk, qb, same) > workspace_bytes) return PIO_E_WORKSPACE;
     const pio_tensor3_t q1 = qb ? first_batch(*iq) : *iq;
-    PIO_TRY(layernorm_cast_launch(q1, nullptr, p.xq16, pad8(a->q_in), a->dtype, s));
-    PIO_TRY(layernorm_cast_launch(*ik, nullptr, p.xk16, pad8(a->k_in), a->dtype, s));
-    if (!same) PIO_TRY(layernorm_cast_launch(*iv, nullptr, p.xv16, pad8(a->v_in), a->dtype, s));
+    PIO_TRY(cast_pair(q1, nullptr, p.xq16, pad8(a->q_in), a->dtype, s));
+    PIO_TRY(cast_pair(*ik, nullptr, p.xk16, pad8(a->k_in), a->dtype, s));
+    if (!same) PIO_TRY(cast_pair(*iv, nullptr, p.xv16, pad8(a->v_in), a->dtype, s));
     return attention_core(*a, p.xq16, qb, p.xk16, p.xv16, B, Tq, Tk, kv_mask, q_mask, full_mask, attention_bias,
                           nullptr, out, probs_out, p.core, s);
 }
@@ -265,8 +400,8 @@ int pio_attention_fwd(const pio_attention_t *a, const pio_tensor3_t *iq, const p
 size_t pio_mlp_workspace_bytes(const pio_mlp_t *m, int64_t rows) {
     if (!m) return 0;
     Carver c(nullptr);
-    c.take((size_t)rows * pad8(m->in) * 2);
-    c.take((size_t)rows * pad8(m->hidden) * 2);
+    take_pair(c, (size_t)rows * pad8(m->in), m->act_split != 0);
+    take_pair(c, (size_t)rows * pad8(m->hidden), m->act_split != 0);
     return c.off;
 }
 
@@ -278,53 +413,15 @@ int pio_mlp_fwd(const pio_mlp_t *m, const pio_tensor3_t *x, float *out, void *wo
     if (pio_mlp_workspace_bytes(m, rows) > workspace_bytes) return PIO_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     Carver c(workspace);
-    void *x16 = c.take((size_t)rows * pad8(m->in) * 2);
-    void *h16 = c.take((size_t)rows * pad8(m->hidden) * 2);
-    PIO_TRY(layernorm_cast_launch(*x, nullptr, x16, pad8(m->in), m->dtype, s));
+    const Pair x16 = take_pair(c, (size_t)rows * pad8(m->in), m->act_split != 0);
+    const Pair h16 = take_pair(c, (size_t)rows * pad8(m->hidden), m->act_split != 0);
+    PIO_TRY(cast_pair(*x, nullptr, x16, pad8(m->in), m->dtype, s));
     return mlp_core(*m, x16, rows, h16, nullptr, out, s);
 }
 
 // ======================================================================================================
-// SelfAttention.forward
+// SelfAttention.forward / CrossAttention.forward
 // ======================================================================================================
-namespace {
-struct SelfPlan {
-    void *x16, *h16;
-    float *x1;
-    AttnScratch core;
-    size_t carve(void *base, const pio_self_attention_t &sa, int B, int N) {
-        Carver c(base);
-        const int64_t rows = (int64_t)B * N;
-        const int cmax = pad8(sa.attn.q_in) > pad8(sa.mlp.in) ? pad8(sa.attn.q_in) : pad8(sa.mlp.in);
-        x16 = c.take((size_t)rows * cmax * 2);
-        h16 = c.take((size_t)rows * pad8(sa.mlp.hidden) * 2);
-        x1 = (float *)c.take((size_t)rows * sa.attn.out * 4);
-        core.carve(c, sa.attn, B, B, N, N);
-        return c.off;
-    }
-};
-
-int self_attention_run(const pio_self_attention_t &sa, const pio_tensor3_t &x, const uint8_t *kv_mask,
-                       const uint8_t *q_mask, const uint8_t *full_mask, const float *attention_bias, float *out,
-                       float *probs_out, SelfPlan &p, hipStream_t s) {
-    const int B = x.B, N = x.T;
-    const int64_t rows = (int64_t)B * N;
-    if (x.C != sa.attn.q_in || sa.attn.k_in != x.C || sa.attn.v_in != x.C || sa.attn.out != x.C || sa.mlp.in != x.C ||
-        sa.mlp.out != x.C)
-        return PIO_E_SHAPE;  // residual adds need matching widths (the reference raises a RuntimeError)
-    // LN1 -> attention -> + x     (transformer_primitives.py:281-290)
-    PIO_TRY(layernorm_cast_launch(x, &sa.ln1, p.x16, pad8(x.C), sa.attn.dtype, s));
-    const Residual rx = residual_of(x);
-    PIO_TRY(attention_core(sa.attn, p.x16, false, p.x16, p.x16, B, N, N, kv_mask, q_mask, full_mask, attention_bias,
-                           &rx, p.x1, probs_out, p.core, s));
-    // LN2 -> MLP -> + x1          (transformer_primitives.py:292)
-    pio_tensor3_t t1 = {p.x1, (int64_t)N * x.C, x.C, B, N, x.C};
-    PIO_TRY(layernorm_cast_launch(t1, &sa.ln2, p.x16, pad8(x.C), sa.mlp.dtype, s));
-    const Residual r1 = residual_of(t1);
-    return mlp_core(sa.mlp, p.x16, rows, p.h16, &r1, out, s);
-}
-}  // namespace
-
 size_t pio_self_attention_workspace_bytes(const pio_self_attention_t *sa, int32_t B, int32_t N) {
     if (!sa) return 0;
     SelfPlan p;
@@ -340,52 +437,6 @@ int pio_self_attention_fwd(const pio_self_attention_t *sa, const pio_tensor3_t *
     return self_attention_run(*sa, *x, kv_mask, q_mask, full_mask, attention_bias, out, probs_out, p,
                               (hipStream_t)stream);
 }
-
-// ======================================================================================================
-// CrossAttention.forward
-// ======================================================================================================
-namespace {
-struct CrossPlan {
-    void *q16, *kv16, *h16;
-    float *x1;
-    AttnScratch core;
-    bool q_bcast;
-    size_t carve(void *base, const pio_cross_attention_t &ca, int B, int Tq, int Tk, bool qb) {
-        Carver c(base);
-        q_bcast = qb;
-        const int Bq = qb ? 1 : B;
-        const int64_t rows = (int64_t)B * Tq;
-        // q16 is reused for LN2(x1): size it for all B*Tq rows
-        q16 = c.take((size_t)rows * pad8(ca.attn.q_in) * 2);
-        kv16 = c.take((size_t)B * Tk * pad8(ca.attn.k_in) * 2);
-        h16 = c.take((size_t)rows * pad8(ca.mlp.hidden) * 2);
-        x1 = (float *)c.take((size_t)rows * ca.attn.out * 4);
-        core.carve(c, ca.attn, Bq, B, Tq, Tk);
-        return c.off;
-    }
-};
-
-int cross_attention_run(const pio_cross_attention_t &ca, const pio_tensor3_t &iq, const pio_tensor3_t &ikv,
-                        const uint8_t *kv_mask, const uint8_t *q_mask, const uint8_t *full_mask,
-                        const float *attention_bias, float *out, float *probs_out, CrossPlan &p, hipStream_t s) {
-    const int B = iq.B, Tq = iq.T, Tk = ikv.T;
-    const int64_t rows = (int64_t)B * Tq;
-    if (iq.C != ca.attn.q_in || ikv.C != ca.attn.k_in || ikv.C != ca.attn.v_in || ikv.B != B) return PIO_E_SHAPE;
-    if (ca.attn.out != iq.C || ca.mlp.in != iq.C || ca.mlp.out != iq.C) return PIO_E_SHAPE;
-    // layer_norm_kv, layer_norm_q  (transformer_primitives.py:379-380)
-    PIO_TRY(layernorm_cast_launch(ikv, &ca.ln_kv, p.kv16, pad8(ikv.C), ca.attn.dtype, s));
-    const pio_tensor3_t q1 = p.q_bcast ? first_batch(iq) : iq;
-    PIO_TRY(layernorm_cast_launch(q1, &ca.ln_q, p.q16, pad8(iq.C), ca.attn.dtype, s));
-    const Residual rq = residual_of(iq);
-    PIO_TRY(attention_core(ca.attn, p.q16, p.q_bcast, p.kv16, p.kv16, B, Tq, Tk, kv_mask, q_mask, full_mask,
-                           attention_bias, ca.use_query_residual ? &rq : nullptr, p.x1, probs_out, p.core, s));
-    // x + MLP(LN2(x))  (transformer_primitives.py:401)
-    pio_tensor3_t t1 = {p.x1, (int64_t)Tq * iq.C, iq.C, B, Tq, iq.C};
-    PIO_TRY(layernorm_cast_launch(t1, &ca.ln2, p.q16, pad8(iq.C), ca.mlp.dtype, s));
-    const Residual r1 = residual_of(t1);
-    return mlp_core(ca.mlp, p.q16, rows, p.h16, &r1, out, s);
-}
-}  // namespace
 
 size_t pio_cross_attention_workspace_bytes(const pio_cross_attention_t *ca, int32_t B, int32_t Tq, int32_t Tk) {
     if (!ca) return 0;
@@ -439,7 +490,7 @@ int pio_encoder_fwd(const pio_cross_attention_t *cross, const pio_self_attention
                                     cp, s));
     }
     const pio_tensor3_t z = {out, (int64_t)N * D, D, B, N, D};
-    for (int blk = 0; blk < num_blocks; ++blk) {      // perceiver.py:104-106: weights shared across blocks
+    for (int blk = 0; blk < num_blocks; ++blk) {  // perceiver.py:104-106: weights shared across blocks
         for (int l = 0; l < L; ++l) {
             SelfPlan sp;
             sp.carve(workspace, layers[l], B, N);
@@ -452,27 +503,6 @@ int pio_encoder_fwd(const pio_cross_attention_t *cross, const pio_self_attention
 // ======================================================================================================
 // PerceiverDecoder.forward
 // ======================================================================================================
-namespace {
-struct DecoderPlan {
-    CrossPlan cp;
-    float *y;
-    void *y16;
-    size_t carve(void *base, const pio_cross_attention_t &cross, const pio_linear_t *fin, int B, int Q, int N,
-                 bool qb) {
-        Carver c(base);
-        const int64_t rows = (int64_t)B * Q;
-        y = nullptr;
-        y16 = nullptr;
-        if (fin) {
-            y = (float *)c.take((size_t)rows * cross.attn.q_in * 4);
-            y16 = c.take((size_t)rows * pad8(cross.attn.q_in) * 2);
-        }
-        const size_t inner = cp.carve(base ? (char *)base + c.off : nullptr, cross, B, Q, N, qb);
-        return c.off + inner;
-    }
-};
-}  // namespace
-
 size_t pio_decoder_workspace_bytes(const pio_cross_attention_t *cross, const pio_linear_t *final_layer, int32_t B,
                                    int32_t Q, int32_t N) {
     if (!cross) return 0;
@@ -497,10 +527,11 @@ int pio_decoder_fwd(const pio_cross_attention_t *cross, const pio_linear_t *fina
     if (!final_layer) return PIO_OK;
     // perceiver.py:178-179: final nn.Linear on every query row
     if (final_layer->k != pad8(query->C)) return PIO_E_SHAPE;
+    if (cross->mlp.act_split && !final_layer->w_lo) return PIO_E_ARG;
     const pio_tensor3_t ty = {y, (int64_t)Q * query->C, query->C, B, Q, query->C};
-    PIO_TRY(layernorm_cast_launch(ty, nullptr, p.y16, pad8(query->C), cross->attn.dtype, s));
-    return linear_fwd(*final_layer, cross->attn.dtype, p.y16, (int64_t)B * Q, out, true, final_out, final_out, 0,
-                      nullptr, s);
+    PIO_TRY(cast_pair(ty, nullptr, p.y16, pad8(query->C), cross->attn.dtype, s));
+    return linear_fwd(*final_layer, cross->attn.dtype, p.y16, (int64_t)B * Q, out, nullptr, true, final_out, final_out,
+                      0, nullptr, s);
 }
 
 }  // extern "C"

@@ -44,10 +44,10 @@ int pio_pack_linear(const float *w, const float *bias, int32_t out, int32_t in, 
                               dtype, (hipStream_t)stream);
 }
 
-int pio_layernorm_cast(const pio_tensor3_t *x, const pio_layernorm_t *ln, void *y, int32_t c_pad, int32_t dtype,
-                       void *stream) {
+int pio_layernorm_cast(const pio_tensor3_t *x, const pio_layernorm_t *ln, void *y, void *y_lo, int32_t c_pad,
+                       int32_t dtype, void *stream) {
     if (!x) return PIO_E_ARG;
-    return layernorm_cast_launch(*x, ln, y, c_pad, dtype, (hipStream_t)stream);
+    return layernorm_cast_launch(*x, ln, y, y_lo, c_pad, dtype, (hipStream_t)stream);
 }
 
 int pio_gemm_nt(const pio_gemm_t *g, void *stream) {
@@ -55,10 +55,10 @@ int pio_gemm_nt(const pio_gemm_t *g, void *stream) {
     return gemm_nt_launch(*g, (hipStream_t)stream);
 }
 
-int pio_softmax_rows(const float *S, int64_t lds, void *P, int64_t ldp, int32_t B, int32_t H, int32_t Tq, int32_t Tk,
-                     float scale, const uint8_t *kv_mask, const uint8_t *q_mask, const uint8_t *full_mask,
+int pio_softmax_rows(const float *S, int64_t lds, void *P, void *P_lo, int64_t ldp, int32_t B, int32_t H, int32_t Tq,
+                     int32_t Tk, float scale, const uint8_t *kv_mask, const uint8_t *q_mask, const uint8_t *full_mask,
                      const float *bias, int32_t dtype, void *stream) {
-    return softmax_rows_launch(S, lds, P, ldp, B, H, Tq, Tk, scale, kv_mask, q_mask, full_mask, bias, dtype, nullptr,
+    return softmax_rows_launch(S, lds, P, P_lo, ldp, B, H, Tq, Tk, scale, kv_mask, q_mask, full_mask, bias, dtype, nullptr,
                                (hipStream_t)stream);
 }
 

@@ -80,13 +80,15 @@ __global__ __launch_bounds__(256) void layernorm_cast_kernel(const float *__rest
                                                              int64_t stride_t, int T, int64_t rows, int C,
                                                              const float *__restrict__ gamma,
                                                              const float *__restrict__ beta, float eps,
-                                                             typename Op<DT>::T *__restrict__ y, int c_pad) {
+                                                             typename Op<DT>::T *__restrict__ y,
+                                                             typename Op<DT>::T *__restrict__ y_lo, int c_pad) {
     typedef typename Op<DT>::T OT;
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const float *xr = x + (row / T) * stride_b + (row % T) * stride_t;
     OT *yr = y + row * (int64_t)c_pad;
+    OT *ylr = y_lo ? y_lo + row * (int64_t)c_pad : nullptr;
     float mean = 0.f, rstd = 1.f;
     if (NORM) {
         float s = 0.f;
@@ -119,23 +121,24 @@ __global__ __launch_bounds__(256) void layernorm_cast_kernel(const float *__rest
     }
     if (VEC) {
         for (int i = lane * 4; i < c_pad; i += 256) {
-            typename Op<DT>::V4 o;
+            f32x4 f = {0.f, 0.f, 0.f, 0.f};
             if (i < C) {
-                const f32x4 v = *(const f32x4 *)(xr + i);
+                f = *(const f32x4 *)(xr + i);
                 if (NORM) {
                     const f32x4 g = *(const f32x4 *)(gamma + i);
                     const f32x4 b = *(const f32x4 *)(beta + i);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) o[j] = Op<DT>::from_f32((v[j] - mean) * rstd * g[j] + b[j]);
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) o[j] = Op<DT>::from_f32(v[j]);
+                    for (int j = 0; j < 4; ++j) f[j] = (f[j] - mean) * rstd * g[j] + b[j];
                 }
-            } else {
+            }
+            typename Op<DT>::V4 o, l;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = Op<DT>::from_f32(0.f);
+            for (int j = 0; j < 4; ++j) {
+                o[j] = Op<DT>::from_f32(f[j]);
+                l[j] = Op<DT>::from_f32(f[j] - Op<DT>::to_f32(o[j]));
             }
             *(typename Op<DT>::V4 *)(yr + i) = o;
+            if (ylr) *(typename Op<DT>::V4 *)(ylr + i) = l;
         }
     } else {
         for (int i = lane; i < c_pad; i += 64) {
@@ -144,19 +147,21 @@ __global__ __launch_bounds__(256) void layernorm_cast_kernel(const float *__rest
                 v = xr[i];
                 if (NORM) v = (v - mean) * rstd * gamma[i] + beta[i];
             }
-            yr[i] = Op<DT>::from_f32(v);
+            const OT h = Op<DT>::from_f32(v);
+            yr[i] = h;
+            if (ylr) ylr[i] = Op<DT>::from_f32(v - Op<DT>::to_f32(h));
         }
     }
 }
 
-int layernorm_cast_launch(const pio_tensor3_t &x, const pio_layernorm_t *ln, void *y, int c_pad, int dtype,
-                          hipStream_t s) {
+int layernorm_cast_launch(const pio_tensor3_t &x, const pio_layernorm_t *ln, void *y, void *y_lo, int c_pad,
+                          int dtype, hipStream_t s) {
     if (!x.data || !y) return PIO_E_ARG;
     if (x.B <= 0 || x.T <= 0 || x.C <= 0 || c_pad < x.C || (c_pad % 8)) return PIO_E_SHAPE;
     if (ln && (ln->c != x.C || !ln->gamma || !ln->beta)) return PIO_E_SHAPE;
     const int64_t rows = (int64_t)x.B * x.T;
     const bool vec = (x.C % 4 == 0) && (((uintptr_t)x.data & 15) == 0) && (x.stride_b % 4 == 0) &&
-                     (x.stride_t % 4 == 0) && (((uintptr_t)y & 7) == 0) &&
+                     (x.stride_t % 4 == 0) && (((uintptr_t)y & 7) == 0) && (((uintptr_t)y_lo & 7) == 0) &&
                      (!ln || ((((uintptr_t)ln->gamma) & 15) == 0 && (((uintptr_t)ln->beta) & 15) == 0));
     const unsigned blocks = (unsigned)((rows + 3) / 4);
     const float eps = ln ? ln->eps : 0.f;
@@ -164,7 +169,8 @@ int layernorm_cast_launch(const pio_tensor3_t &x, const pio_layernorm_t *ln, voi
     const float *b = ln ? ln->beta : nullptr;
 #define PIO_LN_LAUNCH(DTV, VECV, NORMV)                                                                          \
     hipLaunchKernelGGL((layernorm_cast_kernel<DTV, VECV, NORMV>), dim3(blocks), dim3(256), 0, s, x.data,          \
-                       x.stride_b, x.stride_t, x.T, rows, x.C, g, b, eps, (typename Op<DTV>::T *)y, c_pad)
+                       x.stride_b, x.stride_t, x.T, rows, x.C, g, b, eps, (typename Op<DTV>::T *)y,                \
+                       (typename Op<DTV>::T *)y_lo, c_pad)
     if (dtype == PIO_DT_F16) {
         if (ln) { if (vec) PIO_LN_LAUNCH(PIO_DT_F16, true, true); else PIO_LN_LAUNCH(PIO_DT_F16, false, true); }
         else    { if (vec) PIO_LN_LAUNCH(PIO_DT_F16, true, false); else PIO_LN_LAUNCH(PIO_DT_F16, false, false); }
@@ -187,7 +193,7 @@ int layernorm_cast_launch(const pio_tensor3_t &x, const pio_layernorm_t *ln, voi
 struct SoftmaxParams {
     const float *S;
     int64_t lds;
-    void *P;
+    void *P, *P_lo;
     int64_t ldp;
     int B, H, Tq, Tk;
     float scale;
@@ -224,6 +230,7 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const SoftmaxParams p
     const uint8_t *fm = p.full_mask ? p.full_mask + ((int64_t)b * p.Tq + i) * p.Tk : nullptr;
     const bool qok = p.q_mask ? p.q_mask[(int64_t)b * p.Tq + i] != 0 : true;
     OT *pr = (OT *)p.P + row * p.ldp;
+    OT *plr = p.P_lo ? (OT *)p.P_lo + row * p.ldp : nullptr;
     float *po = p.probs ? p.probs + row * (int64_t)p.Tk : nullptr;
 
     auto valid = [&](int j) -> bool { return qok && (!km || km[j]) && (!fm || fm[j]); };
@@ -255,17 +262,19 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const SoftmaxParams p
     for (int j = t0; j < (int)p.ldp; j += tstep) {
         float v = 0.f;
         if (j < p.Tk && any && valid(j)) v = __expf(score(j) - m) * inv;
-        pr[j] = Op<DT>::from_f32(v);
+        const OT h = Op<DT>::from_f32(v);
+        pr[j] = h;
+        if (plr) plr[j] = Op<DT>::from_f32(v - Op<DT>::to_f32(h));
         if (po && j < p.Tk) po[j] = any ? v : uni;  // reference returns the un-wiped (uniform) matrix
     }
 }
 
-int softmax_rows_launch(const float *S, int64_t lds, void *P, int64_t ldp, int B, int H, int Tq, int Tk,
+int softmax_rows_launch(const float *S, int64_t lds, void *P, void *P_lo, int64_t ldp, int B, int H, int Tq, int Tk,
                         float scale, const uint8_t *kv_mask, const uint8_t *q_mask, const uint8_t *full_mask,
                         const float *bias, int dtype, float *probs_out, hipStream_t s) {
     if (!S || !P) return PIO_E_ARG;
     if (B <= 0 || H <= 0 || Tq <= 0 || Tk <= 0 || ldp < Tk || lds < Tk) return PIO_E_SHAPE;
-    SoftmaxParams p{S, lds, P, ldp, B, H, Tq, Tk, scale, kv_mask, q_mask, full_mask, bias, probs_out};
+    SoftmaxParams p{S, lds, P, P_lo, ldp, B, H, Tq, Tk, scale, kv_mask, q_mask, full_mask, bias, probs_out};
     const int64_t rows = (int64_t)B * H * Tq;
     if (Tk <= 2048) {
         const unsigned blocks = (unsigned)((rows + 3) / 4);

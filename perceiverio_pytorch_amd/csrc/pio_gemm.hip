@@ -21,8 +21,10 @@ namespace pio {
 __device__ __attribute__((aligned(16))) uint32_t g_zero_chunk[4] = {0, 0, 0, 0};
 
 struct GemmParams {
-    const void *A, *B, *A2, *B2;  // second-pass operands (== A / B unless a *_lo image is given)
-    void *C;
+    const void *A, *B;
+    int64_t dA1, dB1, dA2, dB2;  // element offsets of the pass-1 / pass-2 operands relative to A / B
+    int npass;                   // 1..3 K sweeps accumulating into the same registers
+    void *C, *C_lo;
     int M, N, K;
     int64_t lda, ldb, ldc;
     int nh;
@@ -43,7 +45,7 @@ constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand tile
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
-template <int DT, bool LO>
+template <int DT>
 __global__ __launch_bounds__(256) void gemm_nt_128(const GemmParams p) {
     typedef typename Op<DT>::T T;
     typedef typename Op<DT>::V8 V8;
@@ -61,16 +63,12 @@ __global__ __launch_bounds__(256) void gemm_nt_128(const GemmParams p) {
 
     const T *A = (const T *)p.A + zb * p.sAb + zh * p.sAh;
     const T *B = (const T *)p.B + zb * p.sBb + zh * p.sBh;
-    const T *A2 = LO ? (const T *)p.A2 + zb * p.sAb + zh * p.sAh : nullptr;
-    const T *B2 = LO ? (const T *)p.B2 + zb * p.sBb + zh * p.sBh : nullptr;
 
     // ---- staging addresses: wave w, piece i covers tile rows (w*4+i)*8 .. +8, lane -> (row, 16-B slot)
     const int srow = lane >> 3;
     const int sslot = lane & 7;
     const T *a_src[4];
     const T *b_src[4];
-    const T *a2_src[4];
-    const T *b2_src[4];
     int s_koff[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -83,24 +81,24 @@ __global__ __launch_bounds__(256) void gemm_nt_128(const GemmParams p) {
         gn = gn < p.N ? gn : p.N - 1;
         a_src[i] = A + (int64_t)gm * p.lda + c * 8;
         b_src[i] = B + (int64_t)gn * p.ldb + c * 8;
-        a2_src[i] = LO ? A2 + (int64_t)gm * p.lda + c * 8 : nullptr;
-        b2_src[i] = LO ? B2 + (int64_t)gn * p.ldb + c * 8 : nullptr;
     }
     const T *zsrc = (const T *)g_zero_chunk;
 
     const int nk1 = (p.K + BK - 1) / BK;
-    const int nk = LO ? 2 * nk1 : nk1;
+    const int nk = p.npass * nk1;
 
     auto stage = [&](int kt, int buf) {
-        const bool lo = LO && kt >= nk1;
-        const int k0 = (lo ? kt - nk1 : kt) * BK;
+        const int pass = (kt >= nk1) + (kt >= 2 * nk1);   // wave-uniform
+        const int k0 = (kt - pass * nk1) * BK;
+        const int64_t dA = pass == 0 ? 0 : (pass == 1 ? p.dA1 : p.dA2);
+        const int64_t dB = pass == 0 ? 0 : (pass == 1 ? p.dB1 : p.dB2);
         char *abase = smem + buf * TILE_BYTES;
         char *bbase = smem + (2 + buf) * TILE_BYTES;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const bool kin = (k0 + s_koff[i]) < p.K;
-            const T *sa = kin ? ((lo ? a2_src[i] : a_src[i]) + k0) : zsrc;
-            const T *sb = kin ? ((lo ? b2_src[i] : b_src[i]) + k0) : zsrc;
+            const T *sa = kin ? (a_src[i] + k0 + dA) : zsrc;
+            const T *sb = kin ? (b_src[i] + k0 + dB) : zsrc;
             const int piece = (wave * 4 + i) * 1024;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)sa,
                                              (__attribute__((address_space(3))) void *)(abase + piece), 16, 0, 0);
@@ -197,10 +195,22 @@ __global__ __launch_bounds__(256) void gemm_nt_128(const GemmParams p) {
                     typename Op<DT>::V4 h = {Op<DT>::from_f32(v[0]), Op<DT>::from_f32(v[1]), Op<DT>::from_f32(v[2]),
                                              Op<DT>::from_f32(v[3])};
                     *(typename Op<DT>::V4 *)(crow + n0) = h;
+                    if (p.C_lo) {
+                        typename Op<DT>::V4 l;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) l[r] = Op<DT>::from_f32(v[r] - Op<DT>::to_f32(h[r]));
+                        *(typename Op<DT>::V4 *)((T *)p.C_lo + coffz + (int64_t)m * p.ldc + n0) = l;
+                    }
                 } else {
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        if (n0 + r < p.n_store) crow[n0 + r] = Op<DT>::from_f32(v[r]);
+                        if (n0 + r < p.n_store) {
+                            const T h = Op<DT>::from_f32(v[r]);
+                            crow[n0 + r] = h;
+                            if (p.C_lo)
+                                ((T *)p.C_lo + coffz + (int64_t)m * p.ldc)[n0 + r] =
+                                    Op<DT>::from_f32(v[r] - Op<DT>::to_f32(h));
+                        }
                 }
             }
         }
@@ -213,7 +223,8 @@ int gemm_nt_launch(const pio_gemm_t &g, hipStream_t s) {
     if (g.K % 8) return PIO_E_SHAPE;
     if (g.batch % g.nh) return PIO_E_SHAPE;
     if ((g.lda % 8) || (g.ldb % 8) || (g.sAb % 8) || (g.sAh % 8) || (g.sBb % 8) || (g.sBh % 8)) return PIO_E_ALIGN;
-    if (((uintptr_t)g.A & 15) || ((uintptr_t)g.B & 15) || ((uintptr_t)g.A_lo & 15) || ((uintptr_t)g.B_lo & 15))
+    if (((uintptr_t)g.A & 15) || ((uintptr_t)g.B & 15) || ((uintptr_t)g.A_lo & 15) || ((uintptr_t)g.B_lo & 15) ||
+        ((uintptr_t)g.C_lo & 7))
         return PIO_E_ALIGN;
     if (g.batch > 65535) return PIO_E_SHAPE;
     if (g.bias_mode && !g.bias) return PIO_E_ARG;
@@ -221,8 +232,16 @@ int gemm_nt_launch(const pio_gemm_t &g, hipStream_t s) {
 
     GemmParams p;
     p.A = g.A; p.B = g.B; p.C = g.C;
-    p.A2 = g.A_lo ? g.A_lo : g.A;
-    p.B2 = g.B_lo ? g.B_lo : g.B;
+    p.C_lo = g.out_f32 ? nullptr : g.C_lo;
+    // K sweeps: (A,B) [+ (A,B_lo)] [+ (A_lo,B)]  -- the dropped A_lo*B_lo term is ~2^-22 relative
+    p.npass = 1;
+    p.dA1 = p.dB1 = p.dA2 = p.dB2 = 0;
+    auto delta = [](const void *lo, const void *hi) { return (int64_t)(((intptr_t)lo - (intptr_t)hi) / 2); };
+    if (g.B_lo) { p.dB1 = delta(g.B_lo, g.B); p.npass = 2; }
+    if (g.A_lo) {
+        if (p.npass == 1) { p.dA1 = delta(g.A_lo, g.A); p.npass = 2; }
+        else              { p.dA2 = delta(g.A_lo, g.A); p.npass = 3; }
+    }
     p.M = g.M; p.N = g.N; p.K = g.K;
     p.lda = g.lda; p.ldb = g.ldb; p.ldc = g.ldc;
     p.nh = g.nh;
@@ -242,14 +261,8 @@ int gemm_nt_launch(const pio_gemm_t &g, hipStream_t s) {
 
     dim3 grid((unsigned)(tiles_m * p.tiles_n), (unsigned)g.batch, 1);
     dim3 block(256, 1, 1);
-    const bool lo = g.B_lo != nullptr || g.A_lo != nullptr;
-    if (g.dtype == PIO_DT_F16) {
-        if (lo) hipLaunchKernelGGL((gemm_nt_128<PIO_DT_F16, true>), grid, block, 0, s, p);
-        else    hipLaunchKernelGGL((gemm_nt_128<PIO_DT_F16, false>), grid, block, 0, s, p);
-    } else {
-        if (lo) hipLaunchKernelGGL((gemm_nt_128<PIO_DT_BF16, true>), grid, block, 0, s, p);
-        else    hipLaunchKernelGGL((gemm_nt_128<PIO_DT_BF16, false>), grid, block, 0, s, p);
-    }
+    if (g.dtype == PIO_DT_F16) hipLaunchKernelGGL((gemm_nt_128<PIO_DT_F16>), grid, block, 0, s, p);
+    else                       hipLaunchKernelGGL((gemm_nt_128<PIO_DT_BF16>), grid, block, 0, s, p);
     return launch_status();
 }
 

@@ -67,9 +67,9 @@ static inline int launch_status() {
 
 // ---- internal launchers (defined in the .hip files) ---------------------------------------------
 int gemm_nt_launch(const pio_gemm_t &g, hipStream_t s);
-int layernorm_cast_launch(const pio_tensor3_t &x, const pio_layernorm_t *ln, void *y, int c_pad, int dtype,
-                          hipStream_t s);
-int softmax_rows_launch(const float *S, int64_t lds, void *P, int64_t ldp, int B, int H, int Tq, int Tk,
+int layernorm_cast_launch(const pio_tensor3_t &x, const pio_layernorm_t *ln, void *y, void *y_lo, int c_pad,
+                          int dtype, hipStream_t s);
+int softmax_rows_launch(const float *S, int64_t lds, void *P, void *P_lo, int64_t ldp, int B, int H, int Tq, int Tk,
                         float scale, const uint8_t *kv_mask, const uint8_t *q_mask, const uint8_t *full_mask,
                         const float *bias, int dtype, float *probs_out, hipStream_t s);
 int pack_linear_launch(const float *w, const float *bias, int out, int in, int64_t ldw, int row_heads,

@@ -124,7 +124,7 @@ class Attention(_HipModule):
 
     # ---- packed descriptor -------------------------------------------------------------------
     def _build_desc(self):
-        dtype, two = R.policy_dtype()
+        dtype, two, split = R.policy_dtype()
         H = self._num_heads
         q = R.PackedLinear(self.proj_q.weight, self.proj_q.bias, H, 1, dtype, two)
         k = R.PackedLinear(self.proj_k.weight, self.proj_k.bias, H, 1, dtype, two)
@@ -133,7 +133,7 @@ class Attention(_HipModule):
         dk, dv = self._qk_channels_per_head, self._v_channels_per_head
         d = L.Attention(q.desc, k.desc, v.desc, o.desc, H, dk, dv, R.pad8(dk), R.pad8(dv),
                         self.proj_q.in_features, self.proj_k.in_features, self.proj_v.in_features,
-                        self.final.out_features, dtype)
+                        self.final.out_features, dtype, int(split))
         return d, [q, k, v, o]
 
     def _params(self):
@@ -194,10 +194,11 @@ class MLP(_HipModule):
         self.dropout = nn.Dropout(dropout_prob)
 
     def _build_desc(self):
-        dtype, two = R.policy_dtype()
+        dtype, two, split = R.policy_dtype()
         f1 = R.PackedLinear(self.fc1.weight, self.fc1.bias, 1, 1, dtype, two)
         f2 = R.PackedLinear(self.fc2.weight, self.fc2.bias, 1, 1, dtype, two)
-        d = L.Mlp(f1.desc, f2.desc, self.fc1.in_features, self.fc1.out_features, self.fc2.out_features, dtype)
+        d = L.Mlp(f1.desc, f2.desc, self.fc1.in_features, self.fc1.out_features, self.fc2.out_features, dtype,
+                  int(split))
         return d, [f1, f2]
 
     def _params(self):
