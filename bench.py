@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""Headline benchmark: PerceiverIO forward hot path, ImageNet-224 (conv preprocessing) configuration.
+
+One "step" = one pass of the hot path over one batch of synthetic input that is already resident in HBM:
+    inputs [B,3136,322] fp32  ->  PerceiverEncoder (cross-attend into 512x1024 latents, 8 blocks x 6
+    weight-shared self-attends)  ->  PerceiverDecoder (1000 learned queries x 1024, query residual, final
+    Linear 1024->1000)  ->  logits of query row 0 (ClassificationPostprocessor, postprocessors.py:187)
+with B = 32 per GPU (BASELINE.json configs[1]).  Every decoder row is computed (as the reference does).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (one rank per GPU, RCCL)
+
+Rank 0 prints ONE JSON line (see README/DESIGN.md for the fields).  Extra objects:
+  roofline     -- the dominant kernel (the linear-layer MFMA GEMM): ALGORITHMIC flops / device time measured
+                  with HIP events around every launch of that kernel in an instrumented repeat of the step
+  cpu_baseline -- the numpy oracle ("port") timed on this host's cores on a bounded sample (rank 0, N=1 only)
+  parity       -- in-run check of the same model at B=2 against the committed reference golden
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+CFG = dict(M=3136, C=322, N=512, D=1024, L=6, blocks=8, xh=1, sh=8, Q=1000, Dq=1024, out=1000)
+# algorithmic GFLOP per sample (2*m*n*k per product, reference formulation)
+GFLOP_PER_SAMPLE = 381.65
+MFMA_PEAK_TFLOPS = 2500.0    # dense fp16/bf16, MI355X_MICROARCH.md chip table
+SEED = 21                    # same generator seed as the committed golden "encdec_imagenet_b2"
+
+
+def build(dev, policy):
+    import perceiver_oracle as O
+    import perceiverio_pytorch_amd as P
+    from perceiverio_pytorch_amd.perceiver import PerceiverDecoder, PerceiverEncoder
+    P.set_precision_policy(policy)
+    p_enc = O.gen_encoder(CFG["C"], CFG["N"], CFG["D"], CFG["L"], SEED)
+    p_dec = O.gen_decoder(CFG["Dq"], CFG["D"], CFG["out"], SEED + 1)
+    qtab = O.gen_tensor("query_table", (CFG["Q"], CFG["Dq"]), SEED, "table")
+    enc = PerceiverEncoder(CFG["C"], CFG["L"], CFG["blocks"], CFG["N"], CFG["D"], num_self_attend_heads=CFG["sh"])
+    dec = PerceiverDecoder(CFG["Dq"], CFG["out"], CFG["D"], use_query_residual=True)
+    enc.load_state_dict({k: torch.from_numpy(v) for k, v in p_enc.items()}, strict=True)
+    dec.load_state_dict({k: torch.from_numpy(v) for k, v in p_dec.items()}, strict=True)
+    return enc.to(dev).eval(), dec.to(dev).eval(), torch.from_numpy(qtab).to(dev), (p_enc, p_dec, qtab)
+
+
+def forward(enc, dec, qtab, x):
+    z = enc(x, enc.latents(x))
+    y = dec(torch.broadcast_to(qtab[None], (x.shape[0],) + qtab.shape), z)
+    return y
+
+
+def parity_check(enc, dec, qtab, dev):
+    """B=2 run on the golden's seeded input vs the reference float32 output frozen in tests/golden."""
+    from cases import _rand
+    g = np.load(os.path.join(ROOT, "tests", "golden", "encdec_imagenet_b2.npz"))
+    x = torch.from_numpy(_rand("encdec_imagenet_b2" + "x", (2, CFG["M"], CFG["C"]), SEED)).to(dev)
+    with torch.inference_mode():
+        y = forward(enc, dec, qtab, x)
+    sub = y[:, torch.from_numpy(g["out_rows"]).to(dev), :].cpu().numpy().astype(np.float64)
+    d = sub - g["out"].astype(np.float64)
+    rl2 = float(np.sqrt((d * d).sum()) / np.sqrt((g["out"].astype(np.float64) ** 2).sum()))
+    rmax = float(np.abs(d).max() / float(g["out_absmax"]))
+    return rl2, rmax
+
+
+def cpu_baseline(params, sample_b):
+    import perceiver_oracle as O
+    from cases import _rand
+    p_enc, p_dec, qtab = params
+    kw = dict(num_blocks=CFG["blocks"], num_self_attends_per_block=CFG["L"], num_cross_attend_heads=1,
+              num_self_attend_heads=CFG["sh"], encoder_query_residual=True, decoder_heads=1,
+              decoder_query_residual=True, final_project=True)
+    x = _rand("cpu_baseline_x", (sample_b, CFG["M"], CFG["C"]), SEED)
+    O.encode_decode(p_enc, p_dec, x[:1], qtab, **kw)            # warm-up (BLAS threads, page-in)
+    t0 = time.perf_counter()
+    O.encode_decode(p_enc, p_dec, x, qtab, **kw)
+    dt = time.perf_counter() - t0
+    return sample_b / dt, dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32, help="samples per GPU per step")
+    ap.add_argument("--policy", default=os.environ.get("PIO_BENCH_POLICY", "fp16"))
+    ap.add_argument("--cpu-sample", type=int, default=4, help="batch of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--no-parity", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+        dist = dist_
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # nccl == RCCL on ROCm
+
+    import perceiverio_pytorch_amd as P
+    from perceiverio_pytorch_amd import _lib as L
+    lib = P.lib()
+    assert lib.pio_arch_ok() == 1, "libpio_hip.so is gfx950-only"
+
+    enc, dec, qtab, params = build(dev, args.policy)
+    B = args.batch
+    gen = torch.Generator(device="cpu").manual_seed(1000 + rank)
+    x = torch.randn(B, CFG["M"], CFG["C"], generator=gen).to(dev)          # resident in HBM before timing
+
+    parity = None
+    if not args.no_parity and rank == 0:
+        rl2, rmax = parity_check(enc, dec, qtab, dev)
+        parity = {"relL2": rl2, "max_abs_over_absmax": rmax, "tol": 1e-3, "case": "encdec_imagenet_b2 (B=2)",
+                  "ok": bool(rl2 <= 1e-3 and rmax <= 1e-3)}
+        if not parity["ok"]:
+            raise SystemExit(f"parity gate failed for policy {args.policy}: {parity}")
+
+    gathered = [torch.empty(B, CFG["out"], device=dev) for _ in range(world)] if world > 1 else None
+
+    def step():
+        y = forward(enc, dec, qtab, x)
+        logits = y[:, 0, :]                                   # ClassificationPostprocessor keeps query row 0
+        if world > 1:
+            dist.all_gather(gathered, logits.contiguous())    # the path's only collective (RCCL over xGMI)
+        return logits
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.inference_mode():
+        for _ in range(args.warmup):
+            step()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        sync()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+
+        # ---- instrumented repeat: HIP events around every kernel launch (same stream), per kernel class ----
+        nprof = max(1, min(3, args.steps))
+        L.check(lib.pio_prof_begin(4096 * nprof), "pio_prof_begin")
+        for _ in range(nprof):
+            step()
+        ms = (C.c_double * 5)()
+        fl = (C.c_double * 5)()
+        by = (C.c_double * 5)()
+        ln = (C.c_int64 * 5)()
+        nrec = lib.pio_prof_end(ms, fl, by, ln)
+        assert nrec > 0, nrec
+
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * B * args.steps / elapsed
+    names = ["gemm_linear", "gemm_attention", "layernorm_cast", "softmax", "pack"]
+    kernels = {}
+    for i, nm in enumerate(names):
+        if ln[i]:
+            kernels[nm] = {"launches_per_step": ln[i] // nprof, "ms_per_step": ms[i] / nprof,
+                           "avg_us": ms[i] / ln[i] * 1e3,
+                           "algo_tflops": (fl[i] / (ms[i] * 1e-3) / 1e12) if fl[i] else None,
+                           "algo_gbps": by[i] / (ms[i] * 1e-3) / 1e9}
+    g = kernels["gemm_linear"]
+    roofline = {"kernel": "pio::gemm_nt_128<f16,0> (linear layers)", "bound": "mfma",
+                "achieved": g["algo_tflops"], "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": g["algo_tflops"] / MFMA_PEAK_TFLOPS, "traffic": None,
+                "avg_launch_us": g["avg_us"], "launches_per_step": g["launches_per_step"]}
+
+    out = {
+        "metric": "samples/sec PerceiverIO fwd (ImageNet-224 conv cfg, 512x1024 latents, 8x6 self-attends)",
+        "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f16" if args.policy.startswith("fp16") else "bf16", "data": "synthetic",
+        "config": {"workload": "imagenet224_conv hot path: encoder(3136x322 -> 512x1024, 8x6 SA) + decoder(1000 "
+                               "queries) + final Linear, all rows computed", "batch_per_gpu": B,
+                   "global_batch": B * world, "precision_policy": args.policy,
+                   "parallelism": f"dp{world} (batch sharded, all-gather of logits)"},
+        "per_gpu": value / world,
+        "model_algo_tflops": value * GFLOP_PER_SAMPLE / 1e3,
+        "model_mfma_frac": value / world * GFLOP_PER_SAMPLE / 1e3 / MFMA_PEAK_TFLOPS,
+        "roofline": roofline, "kernels": kernels, "parity": parity,
+    }
+    if rank == 0 and world == 1 and args.cpu_sample > 0:
+        v, dt = cpu_baseline(params, args.cpu_sample)
+        out["cpu_baseline"] = {"value": v, "unit": "samples/s", "cores": os.cpu_count(), "kind": "port",
+                               "sample": f"numpy fp32 oracle, same model, B={args.cpu_sample}, one forward "
+                                         f"({dt:.1f} s) after a B=1 warm-up"}
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

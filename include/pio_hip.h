@@ -115,6 +115,16 @@ int pio_version(void);
 int pio_arch_ok(void);
 const char *pio_error_string(int code);
 
+/* --- per-launch timing for benchmarks (NOT thread-safe, off by default) ------------------------ */
+/* classes: 0 linear GEMM, 1 attention (batched) GEMM, 2 layernorm/cast, 3 softmax, 4 pack */
+#define PIO_PROF_CLASSES 5
+/* Start recording a HIP-event pair around every kernel launch (up to max_records launches). */
+int pio_prof_begin(int32_t max_records);
+/* Stop, wait for the recorded launches and sum per class: device milliseconds, ALGORITHMIC flops
+ * (2*M*N*K per product, extra precision sweeps not counted), algorithmic bytes, launch count.
+ * Arrays have PIO_PROF_CLASSES entries (any may be NULL).  Returns the number of records or <0. */
+int pio_prof_end(double *ms, double *flops, double *bytes, int64_t *launches);
+
 /* --- weight packing (one-off, after load_state_dict) ------------------------------------------ */
 /* Round a channel count up to the packing granule (8). */
 int32_t pio_pad8(int32_t c);

@@ -82,6 +82,8 @@ SIGNATURES = {
     "pio_version": (C.c_int, []),
     "pio_arch_ok": (C.c_int, []),
     "pio_error_string": (C.c_char_p, [C.c_int]),
+    "pio_prof_begin": (C.c_int, [_i32]),
+    "pio_prof_end": (C.c_int, [P(C.c_double), P(C.c_double), P(C.c_double), P(C.c_int64)]),
     "pio_pad8": (_i32, [_i32]),
     "pio_packed_weight_bytes": (_sz, [_i32, _i32, _i32, _i32]),
     "pio_pack_linear": (C.c_int, [_vp, _vp, _i32, _i32, _i64, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),

@@ -3,9 +3,75 @@
 
 #include <string.h>
 
+#include <vector>
+
 using namespace pio;
 
+// ---------------------------------------------------------------------------------------------------------
+// per-launch timing (bench only).  One global recorder: NOT thread-safe, never enabled on the product path.
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+struct ProfRec {
+    int cls;
+    double flops, bytes;
+};
+struct Prof {
+    bool on = false;
+    std::vector<hipEvent_t> ev;  // 2 per record
+    std::vector<ProfRec> rec;
+    size_t cap = 0;
+} g_prof;
+}  // namespace
+
+namespace pio {
+ProfScope::ProfScope(int cls, double flops, double bytes, hipStream_t stream) : idx(-1), s(stream) {
+    if (!g_prof.on || g_prof.rec.size() >= g_prof.cap) return;
+    idx = (int)g_prof.rec.size();
+    g_prof.rec.push_back({cls, flops, bytes});
+    (void)hipEventRecord(g_prof.ev[2 * idx], s);
+}
+ProfScope::~ProfScope() {
+    if (idx >= 0) (void)hipEventRecord(g_prof.ev[2 * idx + 1], s);
+}
+}  // namespace pio
+
 extern "C" {
+
+int pio_prof_begin(int32_t max_records) {
+    if (max_records <= 0) return PIO_E_ARG;
+    while (g_prof.ev.size() < (size_t)2 * max_records) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return PIO_E_LAUNCH;
+        g_prof.ev.push_back(e);
+    }
+    g_prof.cap = (size_t)max_records;
+    g_prof.rec.clear();
+    g_prof.on = true;
+    return PIO_OK;
+}
+
+int pio_prof_end(double *ms, double *flops, double *bytes, int64_t *launches) {
+    g_prof.on = false;
+    for (int c = 0; c < PROF_CLASSES; ++c) {
+        if (ms) ms[c] = 0;
+        if (flops) flops[c] = 0;
+        if (bytes) bytes[c] = 0;
+        if (launches) launches[c] = 0;
+    }
+    for (size_t i = 0; i < g_prof.rec.size(); ++i) {
+        if (hipEventSynchronize(g_prof.ev[2 * i + 1]) != hipSuccess) return PIO_E_LAUNCH;
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]) != hipSuccess) return PIO_E_LAUNCH;
+        const ProfRec &r = g_prof.rec[i];
+        if (ms) ms[r.cls] += t;
+        if (flops) flops[r.cls] += r.flops;
+        if (bytes) bytes[r.cls] += r.bytes;
+        if (launches) launches[r.cls] += 1;
+    }
+    const int n = (int)g_prof.rec.size();
+    g_prof.rec.clear();
+    return n;
+}
 
 int pio_version(void) { return PIO_VERSION; }
 

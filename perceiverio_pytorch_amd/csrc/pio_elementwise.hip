@@ -164,6 +164,7 @@ int layernorm_cast_launch(const pio_tensor3_t &x, const pio_layernorm_t *ln, voi
                      (x.stride_t % 4 == 0) && (((uintptr_t)y & 7) == 0) && (((uintptr_t)y_lo & 7) == 0) &&
                      (!ln || ((((uintptr_t)ln->gamma) & 15) == 0 && (((uintptr_t)ln->beta) & 15) == 0));
     const unsigned blocks = (unsigned)((rows + 3) / 4);
+    ProfScope prof(PROF_LAYERNORM, 0.0, (double)rows * (4.0 * x.C + (y_lo ? 4.0 : 2.0) * c_pad), s);
     const float eps = ln ? ln->eps : 0.f;
     const float *g = ln ? ln->gamma : nullptr;
     const float *b = ln ? ln->beta : nullptr;
@@ -276,6 +277,7 @@ int softmax_rows_launch(const float *S, int64_t lds, void *P, void *P_lo, int64_
     if (B <= 0 || H <= 0 || Tq <= 0 || Tk <= 0 || ldp < Tk || lds < Tk) return PIO_E_SHAPE;
     SoftmaxParams p{S, lds, P, P_lo, ldp, B, H, Tq, Tk, scale, kv_mask, q_mask, full_mask, bias, probs_out};
     const int64_t rows = (int64_t)B * H * Tq;
+    ProfScope prof(PROF_SOFTMAX, 0.0, (double)rows * (4.0 * Tk + (P_lo ? 4.0 : 2.0) * ldp), s);
     if (Tk <= 2048) {
         const unsigned blocks = (unsigned)((rows + 3) / 4);
         if (dtype == PIO_DT_F16) hipLaunchKernelGGL((softmax_rows_kernel<PIO_DT_F16, 1>), dim3(blocks), dim3(256), 0, s, p);

@@ -45,7 +45,9 @@ constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand tile
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
-template <int DT>
+// KIND only tags the instantiation (0: one flat [rows,K]x[N,K] linear, 1: batched attention product) so that
+// profilers report the two uses under different kernel names.
+template <int DT, int KIND>
 __global__ __launch_bounds__(256) void gemm_nt_128(const GemmParams p) {
     typedef typename Op<DT>::T T;
     typedef typename Op<DT>::V8 V8;
@@ -261,8 +263,19 @@ int gemm_nt_launch(const pio_gemm_t &g, hipStream_t s) {
 
     dim3 grid((unsigned)(tiles_m * p.tiles_n), (unsigned)g.batch, 1);
     dim3 block(256, 1, 1);
-    if (g.dtype == PIO_DT_F16) hipLaunchKernelGGL((gemm_nt_128<PIO_DT_F16>), grid, block, 0, s, p);
-    else                       hipLaunchKernelGGL((gemm_nt_128<PIO_DT_BF16>), grid, block, 0, s, p);
+    const bool attn = g.batch > 1;
+    const double elems = (double)g.batch * ((double)g.M * g.K + (double)g.N * g.K);
+    ProfScope prof(attn ? PROF_GEMM_ATTN : PROF_GEMM_LINEAR, 2.0 * g.M * g.N * (double)g.K * g.batch,
+                   2.0 * elems + (double)g.batch * g.M * g.N * (g.out_f32 ? 4.0 : 2.0) +
+                       (g.R ? 4.0 * g.M * g.N * g.batch : 0.0),
+                   s);
+    if (g.dtype == PIO_DT_F16) {
+        if (attn) hipLaunchKernelGGL((gemm_nt_128<PIO_DT_F16, 1>), grid, block, 0, s, p);
+        else      hipLaunchKernelGGL((gemm_nt_128<PIO_DT_F16, 0>), grid, block, 0, s, p);
+    } else {
+        if (attn) hipLaunchKernelGGL((gemm_nt_128<PIO_DT_BF16, 1>), grid, block, 0, s, p);
+        else      hipLaunchKernelGGL((gemm_nt_128<PIO_DT_BF16, 0>), grid, block, 0, s, p);
+    }
     return launch_status();
 }
 

@@ -65,6 +65,15 @@ static inline int launch_status() {
     return e == hipSuccess ? PIO_OK : PIO_E_LAUNCH;
 }
 
+// ---- optional per-launch timing for bench.py (pio_prof_begin / pio_prof_end); off by default ----------
+enum { PROF_GEMM_LINEAR = 0, PROF_GEMM_ATTN = 1, PROF_LAYERNORM = 2, PROF_SOFTMAX = 3, PROF_PACK = 4, PROF_CLASSES = 5 };
+struct ProfScope {
+    int idx;
+    hipStream_t s;
+    ProfScope(int cls, double flops, double bytes, hipStream_t stream);
+    ~ProfScope();
+};
+
 // ---- internal launchers (defined in the .hip files) ---------------------------------------------
 int gemm_nt_launch(const pio_gemm_t &g, hipStream_t s);
 int layernorm_cast_launch(const pio_tensor3_t &x, const pio_layernorm_t *ln, void *y, void *y_lo, int c_pad,
