@@ -168,16 +168,16 @@ def main():
         L.check(lib.pio_prof_begin(4096 * nprof), "pio_prof_begin")
         for _ in range(nprof):
             step()
-        ms = (C.c_double * 5)()
-        fl = (C.c_double * 5)()
-        by = (C.c_double * 5)()
-        ln = (C.c_int64 * 5)()
+        ms = (C.c_double * 6)()
+        fl = (C.c_double * 6)()
+        by = (C.c_double * 6)()
+        ln = (C.c_int64 * 6)()
         nrec = lib.pio_prof_end(ms, fl, by, ln)
         assert nrec > 0, nrec
 
     ms_per_step = elapsed / args.steps * 1e3
     value = world * B * args.steps / elapsed
-    names = ["gemm_linear", "gemm_attention", "layernorm_cast", "softmax", "pack"]
+    names = ["gemm_linear", "gemm_batched", "layernorm_cast", "softmax", "pack", "fused_attention"]
     kernels = {}
     for i, nm in enumerate(names):
         if ln[i]:

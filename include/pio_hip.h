@@ -76,6 +76,8 @@ typedef struct pio_attention_t {
     int32_t q_in, k_in, v_in, out; /* logical channel counts (k_in == v_in inside Self/CrossAttention) */
     int32_t dtype;     /* PIO_DT_*                                  */
     int32_t act_split; /* 1: activations are carried as hi+lo pairs too (3 MFMA sweeps, ~fp32 products) */
+    pio_linear_t qk;   /* optional (w_hi may be NULL): proj_q and proj_k stacked along the output rows
+                          [q rows | k rows], used as ONE GEMM when inputs_q and inputs_k are the same tensor */
 } pio_attention_t;
 
 /* MLP (transformer_primitives.py:183-216) */
@@ -116,8 +118,8 @@ int pio_arch_ok(void);
 const char *pio_error_string(int code);
 
 /* --- per-launch timing for benchmarks (NOT thread-safe, off by default) ------------------------ */
-/* classes: 0 linear GEMM, 1 attention (batched) GEMM, 2 layernorm/cast, 3 softmax, 4 pack */
-#define PIO_PROF_CLASSES 5
+/* classes: 0 linear GEMM, 1 batched GEMM, 2 layernorm/cast, 3 softmax, 4 pack, 5 fused attention */
+#define PIO_PROF_CLASSES 6
 /* Start recording a HIP-event pair around every kernel launch (up to max_records launches). */
 int pio_prof_begin(int32_t max_records);
 /* Stop, wait for the recorded launches and sum per class: device milliseconds, ALGORITHMIC flops

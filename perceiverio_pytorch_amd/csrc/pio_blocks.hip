@@ -124,12 +124,23 @@ static int attention_core(const pio_attention_t &a, Pair xq, bool q_bcast, Pair 
                           AttnScratch &w, hipStream_t s) {
     PIO_TRY(check_attention(a));
     const int H = a.heads;
-    const int64_t ldq = (int64_t)H * a.dkp, ldo = (int64_t)H * a.dvp, tkp = pad8(Tk);
+    const int64_t hdk = (int64_t)H * a.dkp, ldo = (int64_t)H * a.dvp, tkp = pad8(Tk);
     const int Bq = q_bcast ? 1 : B;
 
-    // 1/2: Q and K projections (transformer_primitives.py:93-94), head-padded columns
-    PIO_TRY(linear_fwd(a.q, a.dtype, xq, (int64_t)Bq * Tq, w.q16.hi, w.q16.lo, false, 0, ldq, 0, nullptr, s));
-    PIO_TRY(linear_fwd(a.k, a.dtype, xk, (int64_t)B * Tk, w.k16.hi, w.k16.lo, false, 0, ldq, 0, nullptr, s));
+    // 1/2: Q and K projections (transformer_primitives.py:93-94), head-padded columns.  When both read the same
+    //      16-bit input (self-attention) they are ONE GEMM over the stacked [q rows | k rows] weight image: the
+    //      q16 / k16 scratch regions are adjacent, the fused output uses them as one [rows, 2*H*dkp] matrix.
+    const bool fuse_qk = a.qk.w_hi && !a.act_split && !q_bcast && xq.hi == xk.hi && Tq == Tk &&
+                         (char *)w.q16.hi + (size_t)B * Tq * hdk * 2 <= (char *)w.k16.hi && a.qk.n == 2 * hdk;
+    const int64_t ldq = fuse_qk ? 2 * hdk : hdk;
+    const void *k_hi = fuse_qk ? (const void *)((const char *)w.q16.hi + hdk * 2) : w.k16.hi;
+    const void *k_lo = fuse_qk ? nullptr : w.k16.lo;
+    if (fuse_qk) {
+        PIO_TRY(linear_fwd(a.qk, a.dtype, xq, (int64_t)B * Tq, w.q16.hi, nullptr, false, 0, ldq, 0, nullptr, s));
+    } else {
+        PIO_TRY(linear_fwd(a.q, a.dtype, xq, (int64_t)Bq * Tq, w.q16.hi, w.q16.lo, false, 0, ldq, 0, nullptr, s));
+        PIO_TRY(linear_fwd(a.k, a.dtype, xk, (int64_t)B * Tk, w.k16.hi, w.k16.lo, false, 0, ldq, 0, nullptr, s));
+    }
 
     // 3: V^T[b] = Wv * X_v[b]^T + bv (transformer_primitives.py:95) produced directly in the K-contiguous layout
     //    the P*V product wants; the weight is the A operand (batch stride 0), bias is per output ROW.
@@ -155,13 +166,23 @@ static int attention_core(const pio_attention_t &a, Pair xq, bool q_bcast, Pair 
         g.n_store = (int)tkp;
         PIO_TRY(gemm_nt_launch(g, s));
     }
+    // 4-6 fused (flash) when nothing needs the score matrix: no mask / bias / return_matrix, single-sweep
+    //      attention operands, supported head widths.  Otherwise the materialised path below.
+    const bool fused = !a.act_split && !kv_mask && !q_mask && !full_mask && !attention_bias && !probs_out &&
+                       flash_supported(a.dkp, a.dvp);
+    if (fused) {
+        PIO_TRY(flash_attention_launch(a.dtype, a.dkp, a.dvp, a.dk, w.q16.hi, k_hi, w.vt16.hi, w.o16.hi, B, H, Tq,
+                                       Tk, ldq, ldq, tkp, ldo, q_bcast ? 0 : (int64_t)Tq * ldq, (int64_t)Tk * ldq,
+                                       ldo * tkp, (int64_t)Tq * ldo, s));
+        return linear_fwd(a.o, a.dtype, w.o16, (int64_t)B * Tq, out, nullptr, true, a.out, a.out, 0, res, s);
+    }
     // 4: S[b,h] = Q[b,h] K[b,h]^T (transformer_primitives.py:138), fp32 scores
     {
         pio_gemm_t g = gemm_defaults(a.dtype);
         g.A = w.q16.hi;
         g.A_lo = w.q16.lo;
-        g.B = w.k16.hi;
-        g.B_lo = w.k16.lo;
+        g.B = k_hi;
+        g.B_lo = k_lo;
         g.C = w.scores;
         g.M = Tq;
         g.N = Tk;

@@ -1,0 +1,253 @@
+// Fused multi-head attention core for gfx950: O = softmax(Q K^T / sqrt(dk)) V without materialising the
+// score matrix.  Replaces transformer_primitives.py:138-166 (scores, scale, softmax, P.v, head merge) for the
+// un-masked case with per-head widths 32/64/128 (qk) and 32..160 (v) -- the latent self-attention stack.
+//
+// Structure (one workgroup = 4 waves = 128 query rows of one (batch, head); one wave = 32 query rows):
+//   * "swapped" products so that the softmax axis never crosses lanes:
+//       S^T[k][q] = K[k][:] . Q[q][:]      mfma_32x32x16(A = K fragment, B = Q fragment)  -> column q on the lane
+//       O^T[d][q] = V^T[d][:] . P^T[:][q]  mfma_32x32x16(A = V^T fragment, B = P^T)       -> P^T is the S^T
+//     accumulator itself, converted to 16 bit in place (registers 8s..8s+7 are the B fragment of k-step s):
+//     no LDS round trip, no shuffles for P.  Lanes l and l+32 hold the two halves of a column; only the
+//     running max crosses them (one ds_bpermute per 64-key tile), the row sums are combined once at the end.
+//   * Q fragments stay in registers for the whole kernel; K [64 keys][dk] and V^T [dv][64 keys] tiles are
+//     staged HBM -> LDS by LDS-DMA (global_load_lds_dwordx4), double buffered, one barrier per tile, with the
+//     XOR swizzle applied on the source address and on the ds_read side (conflict-free K reads, 2-way V^T reads).
+//   * V is consumed K-contiguous (V^T [dv][keys]), which is exactly what the V projection GEMM writes.
+//   * online softmax in base 2 (scale folded into the exponent constant), fp32 statistics and accumulators.
+#include "pio_internal.h"
+
+namespace pio {
+
+struct FlashParams {
+    const void *Q, *K, *VT;
+    void *O;
+    int Tq, Tk, H;
+    int64_t ldq, ldk, ldvt, ldo;
+    int64_t sQb, sKb, sVb, sOb;  // batch strides (elements); 0 for a batch-invariant Q
+    float scale_log2;            // log2(e) / sqrt(dk)
+};
+
+static __device__ __attribute__((aligned(16))) uint32_t g_zero_chunk_f[4] = {0, 0, 0, 0};
+
+template <int DT, int DK, int DV>
+__global__ __launch_bounds__(256) void flash_attn_kernel(const FlashParams p) {
+    typedef typename Op<DT>::T T;
+    typedef typename Op<DT>::V8 V8;
+    typedef typename Op<DT>::V4 V4;
+    constexpr int KT = 64;                       // keys per tile
+    constexpr int K_TILE = KT * DK * 2;          // bytes
+    constexpr int V_TILE = DV * KT * 2;          // bytes
+    constexpr int KCPR = DK / 8;                 // 16-byte chunks per K row (4, 8, 16)
+    constexpr int KRPB = 16 / KCPR;              // K rows per 256-byte bank row
+    constexpr int K_PIECES = K_TILE / 1024;      // 1-KiB LDS-DMA pieces per tile
+    constexpr int V_PIECES = V_TILE / 1024;
+    constexpr int NDT = DV / 32;                 // 32-row O^T tiles
+    constexpr int NQS = DK / 16;                 // k-steps of the Q.K product
+    __shared__ __attribute__((aligned(16))) char smem[2 * (K_TILE + V_TILE)];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r32 = lane & 31, hh = lane >> 5;
+    const int b = blockIdx.y / p.H, h = blockIdx.y % p.H;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+
+    const T *Qg = (const T *)p.Q + b * p.sQb + (int64_t)h * DK;
+    const T *Kg = (const T *)p.K + b * p.sKb + (int64_t)h * DK;
+    const T *Vg = (const T *)p.VT + b * p.sVb + (int64_t)h * DV * p.ldvt;
+    const T *zsrc = (const T *)g_zero_chunk_f;
+
+    // ---- Q fragments (B operand): lane holds Q[q0 + r32][16*s + 8*hh + 0..7]
+    V8 qf[NQS];
+    {
+        int q = q0 + r32;
+        q = q < p.Tq ? q : p.Tq - 1;
+        const T *qrow = Qg + (int64_t)q * p.ldq + 8 * hh;
+#pragma unroll
+        for (int s = 0; s < NQS; ++s) qf[s] = *(const V8 *)(qrow + 16 * s);
+    }
+
+    const int ntiles = (p.Tk + KT - 1) / KT;
+
+    auto stage = [&](int kt, int buf) {
+        char *kb = smem + buf * (K_TILE + V_TILE);
+        char *vb = kb + K_TILE;
+        const int k0 = kt * KT;
+        // K tile: piece = 64 chunks = 64/KCPR rows
+        for (int pc = wave; pc < K_PIECES; pc += 4) {
+            const int row = pc * (64 / KCPR) + lane / KCPR;
+            const int slot = lane % KCPR;
+            const int c = slot ^ ((row / KRPB) & (KCPR - 1));
+            int key = k0 + row;
+            key = key < p.Tk ? key : p.Tk - 1;
+            const T *src = Kg + (int64_t)key * p.ldk + c * 8;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(kb + pc * 1024), 16, 0, 0);
+        }
+        // V^T tile: rows = dv (128-byte rows, 8 chunks), piece = 8 rows
+        for (int pc = wave; pc < V_PIECES; pc += 4) {
+            const int row = pc * 8 + (lane >> 3);
+            const int slot = lane & 7;
+            const int c = slot ^ ((row >> 1) & 7);
+            const int kcol = k0 + c * 8;
+            const T *src = (kcol < p.ldvt) ? Vg + (int64_t)row * p.ldvt + kcol : zsrc;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(vb + pc * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x16 oacc[NDT];
+#pragma unroll
+    for (int i = 0; i < NDT; ++i)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) oacc[i][j] = 0.f;
+    float m_run = -INFINITY;  // running max (already in base-2 scaled units), identical in lanes l and l+32
+    float l_run = 0.f;        // this lane's partial row sum
+
+    // per-lane read offsets
+    int k_off[2];  // K fragment row byte offsets for the two 32-key halves (chunk part added per step)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) k_off[t] = (32 * t + r32) * (DK * 2);
+    const int k_swz = (r32 / KRPB) & (KCPR - 1);  // 32t is a multiple of 16*KRPB?  (32t + r32)/KRPB & mask:
+    // (32/KRPB) is a multiple of KCPR for every supported DK (KCPR*KRPB = 16 divides 32), so t drops out.
+    const int v_swz = (r32 >> 1) & 7;             // 32*dvt is even and a multiple of 16 rows -> drops out as well
+
+    stage(0, 0);
+    for (int kt = 0; kt < ntiles; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kt + 1 < ntiles) stage(kt + 1, (kt + 1) & 1);
+        const char *kb = smem + (kt & 1) * (K_TILE + V_TILE);
+        const char *vb = kb + K_TILE;
+
+        // ---- S^T = K Q^T for the two 32-key halves
+        f32x16 sacc[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) sacc[t][j] = 0.f;
+#pragma unroll
+            for (int s = 0; s < NQS; ++s) {
+                const int chunk = (2 * s + hh) ^ k_swz;
+                const V8 kf = *(const V8 *)(kb + k_off[t] + chunk * 16);
+                sacc[t] = Op<DT>::mfma32(kf, qf[s], sacc[t]);
+            }
+        }
+        // ---- scale to base 2, mask keys past Tk (last tile only), tile max
+        const bool tail = (kt == ntiles - 1) && (p.Tk % KT != 0);
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                float v = sacc[t][i] * p.scale_log2;
+                if (tail) {
+                    const int key = kt * KT + 32 * t + (i & 3) + 8 * (i >> 2) + 4 * hh;
+                    if (key >= p.Tk) v = -INFINITY;
+                }
+                sacc[t][i] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);  // first tile: exp2(-inf) = 0
+        m_run = m_new;
+        float psum = 0.f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float e = __builtin_amdgcn_exp2f(sacc[t][i] - m_new);
+                sacc[t][i] = e;
+                psum += e;
+            }
+        l_run = l_run * alpha + psum;
+#pragma unroll
+        for (int d = 0; d < NDT; ++d)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) oacc[d][j] *= alpha;
+
+        // ---- P^T fragments: registers 8s..8s+7 of the S^T accumulator are the B operand of k-step s
+        V8 pf[2][2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pf[t][s][j] = Op<DT>::from_f32(sacc[t][8 * s + j]);
+
+        // ---- O^T += V^T P^T.  A fragment element j <-> key 32t + 16s + 8(j>>2) + 4hh + (j&3)
+#pragma unroll
+        for (int d = 0; d < NDT; ++d) {
+            const char *vrow = vb + (32 * d + r32) * 128;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const int g = 8 * t + 4 * s + hh;  // 8-byte granule of keys [4g, 4g+4); second one is g+2
+                    const V4 lo = *(const V4 *)(vrow + ((((g >> 1)) ^ v_swz) << 4) + (g & 1) * 8);
+                    const V4 hi = *(const V4 *)(vrow + ((((g + 2) >> 1) ^ v_swz) << 4) + (g & 1) * 8);
+                    V8 vf;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        vf[j] = lo[j];
+                        vf[4 + j] = hi[j];
+                    }
+                    oacc[d] = Op<DT>::mfma32(vf, pf[t][s], oacc[d]);
+                }
+        }
+    }
+
+    // ---- epilogue: combine the two half-column sums, normalise, store O[q][h*DV + d]
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    const int q = q0 + r32;
+    if (q < p.Tq) {
+        T *orow = (T *)p.O + b * p.sOb + (int64_t)q * p.ldo + (int64_t)h * DV;
+#pragma unroll
+        for (int d = 0; d < NDT; ++d)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                V4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = Op<DT>::from_f32(oacc[d][4 * g4 + j] * inv);
+                *(V4 *)(orow + 32 * d + 8 * g4 + 4 * hh) = o;
+            }
+    }
+}
+
+bool flash_supported(int dkp, int dvp) {
+    return (dkp == 128 && dvp == 128) || (dkp == 64 && dvp == 64) || (dkp == 32 && dvp == 32) ||
+           (dkp == 32 && dvp == 160);
+}
+
+int flash_attention_launch(int dtype, int dkp, int dvp, int dk_logical, const void *Q, const void *K, const void *VT,
+                           void *O, int B, int H, int Tq, int Tk, int64_t ldq, int64_t ldk, int64_t ldvt, int64_t ldo,
+                           int64_t sQb, int64_t sKb, int64_t sVb, int64_t sOb, hipStream_t s) {
+    if (!flash_supported(dkp, dvp)) return PIO_E_SHAPE;
+    if (!Q || !K || !VT || !O) return PIO_E_ARG;
+    if (B <= 0 || H <= 0 || Tq <= 0 || Tk <= 0 || (int64_t)B * H > 65535) return PIO_E_SHAPE;
+    if ((ldq % 8) || (ldk % 8) || (ldvt % 8) || (ldo % 4) || (sQb % 8) || (sKb % 8) || (sVb % 8) || (sOb % 4))
+        return PIO_E_ALIGN;
+    if (((uintptr_t)Q & 15) || ((uintptr_t)K & 15) || ((uintptr_t)VT & 15) || ((uintptr_t)O & 7)) return PIO_E_ALIGN;
+    FlashParams p{Q, K, VT, O, Tq, Tk, H, ldq, ldk, ldvt, ldo, sQb, sKb, sVb, sOb,
+                  1.4426950408889634f / sqrtf((float)dk_logical)};
+    dim3 grid((unsigned)((Tq + 127) / 128), (unsigned)(B * H), 1), block(256, 1, 1);
+    ProfScope prof(PROF_FLASH, 2.0 * B * H * (double)Tq * Tk * (dkp + dvp),
+                   2.0 * B * H * ((double)Tq * (dkp + dvp) + (double)Tk * (dkp + dvp)), s);
+#define PIO_FLASH(DTV, DKV, DVV) hipLaunchKernelGGL((flash_attn_kernel<DTV, DKV, DVV>), grid, block, 0, s, p)
+#define PIO_FLASH_DT(DKV, DVV)                                         \
+    do {                                                               \
+        if (dtype == PIO_DT_F16) PIO_FLASH(PIO_DT_F16, DKV, DVV);      \
+        else PIO_FLASH(PIO_DT_BF16, DKV, DVV);                         \
+    } while (0)
+    if (dkp == 128 && dvp == 128) PIO_FLASH_DT(128, 128);
+    else if (dkp == 64 && dvp == 64) PIO_FLASH_DT(64, 64);
+    else if (dkp == 32 && dvp == 32) PIO_FLASH_DT(32, 32);
+    else PIO_FLASH_DT(32, 160);
+#undef PIO_FLASH_DT
+#undef PIO_FLASH
+    return launch_status();
+}
+
+}  // namespace pio

@@ -37,13 +37,29 @@ struct GemmParams {
     int r_rows;
     int out_f32, n_store;
     int tiles_n;
-    int vec_ok;  // C (and R) rows are 16-byte (fp32) / 8-byte (16-bit) aligned for 4-column vectors
+    int vec_ok;    // C rows are 16-byte (fp32) / 8-byte (16-bit) aligned for 4-column vectors
+    int r_vec;     // residual rows are 16-byte aligned
+    int bias_vec;  // bias is 16-byte aligned
 };
 
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand tile
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// erf by Abramowitz & Stegun 7.1.26 (|abs error| <= 1.5e-7, i.e. fp32-level for GELU): one v_exp, one v_rcp and
+// a 5-term polynomial instead of libm's branchy erff (which cost ~20 % of a K=1024 GEMM's time in the epilogue).
+__device__ __forceinline__ float fast_erf(float x) {
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+    float poly = fmaf(1.061405429f, t, -1.453152027f);
+    poly = fmaf(poly, t, 1.421413741f);
+    poly = fmaf(poly, t, -0.284496736f);
+    poly = fmaf(poly, t, 0.254829592f);
+    poly *= t;
+    const float e = __builtin_amdgcn_exp2f(-ax * ax * 1.4426950408889634f);
+    const float r = 1.0f - poly * e;
+    return copysignf(r, x);
+}
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752440f)); }
 
 // KIND only tags the instantiation (0: one flat [rows,K]x[N,K] linear, 1: batched attention product) so that
 // profilers report the two uses under different kernel names.
@@ -149,43 +165,72 @@ __global__ __launch_bounds__(256) void gemm_nt_128(const GemmParams p) {
         }
     }
 
-    // ---- epilogue: lane holds C[m][n0..n0+3], m = ..+(lane&15), n0 = ..+4*(lane>>4)
-    const int64_t coffz = zb * p.sCb + zh * p.sCh;
+    // ---- epilogue through LDS: the accumulators (lane = one row, 4 consecutive columns) are parked in a
+    // [128][128] fp32 image (16-byte chunks XOR-swizzled by row, conflict-free both ways) so that the
+    // bias / GELU / residual / store pass walks whole rows: a wave touches 2 rows x 512 contiguous bytes
+    // (fp32) or 2 rows x 256 bytes (16-bit) per instruction instead of 16 rows x 64 bytes.
+    __syncthreads();  // every wave is done reading the last operand tile
+    float *cs = (float *)smem;
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
-        const int m = tile_m * BM + wm * 64 + mi * 16 + (lane & 15);
-        if (m >= p.M) continue;
-        const float *rrow = nullptr;
-        if (p.R) {
-            if (p.r_rows > 0)
-                rrow = p.R + (int64_t)(m / p.r_rows) * p.r_stride_b + (int64_t)(m % p.r_rows) * p.ldr;
-            else
-                rrow = p.R + (int64_t)m * p.ldr;
-        }
-        const float bias_m = (p.bias_mode == 2) ? p.bias[m] : 0.f;
+        const int ml = wm * 64 + mi * 16 + (lane & 15);
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
-            const int n0 = tile_n * BN + wn * 64 + ni * 16 + 4 * (lane >> 4);
-            if (n0 >= p.n_store) continue;
-            float v[4];
+            const int c = wn * 16 + ni * 4 + (lane >> 4);
+            *(f32x4 *)(cs + ml * BN + ((c ^ (ml & 31)) << 2)) = acc[mi][ni];
+        }
+    }
+    __syncthreads();
+    const int64_t coffz = zb * p.sCb + zh * p.sCh;
+    const int c = tid & 31;
+    const int n0 = tile_n * BN + c * 4;
+    if (n0 < p.n_store) {
+        const bool nfull = n0 + 3 < p.N;
+        f32x4 bias_n = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias_mode == 1) {
+            if (nfull && p.bias_vec) {
+                bias_n = *(const f32x4 *)(p.bias + n0);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (n0 + r < p.N) bias_n[r] = p.bias[n0 + r];
+            }
+        }
+#pragma unroll 4
+        for (int it = 0; it < 16; ++it) {
+            const int ml = it * 8 + (tid >> 5);
+            const int m = tile_m * BM + ml;
+            if (m >= p.M) break;  // rows are visited in increasing order
+            f32x4 v = *(const f32x4 *)(cs + ml * BN + ((c ^ (ml & 31)) << 2));
+            const float bias_m = (p.bias_mode == 2) ? p.bias[m] : 0.f;
+            const float *rrow = nullptr;
+            if (p.R) {
+                rrow = (p.r_rows > 0)
+                           ? p.R + (int64_t)(m / p.r_rows) * p.r_stride_b + (int64_t)(m % p.r_rows) * p.ldr
+                           : p.R + (int64_t)m * p.ldr;
+            }
+            f32x4 rv = {0.f, 0.f, 0.f, 0.f};
+            if (rrow) {
+                if (nfull && p.r_vec) {
+                    rv = *(const f32x4 *)(rrow + n0);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (n0 + r < p.N) rv[r] = rrow[n0 + r];
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int n = n0 + r;
-                float x = acc[mi][ni][r] * p.alpha;
-                if (n < p.N) {
-                    if (p.bias_mode == 1) x += p.bias[n];
-                    x += bias_m;
-                    if (p.act == 1) x = gelu_erf(x);
-                    if (rrow) x += rrow[n];
-                } else {
-                    x = 0.f;
-                }
-                v[r] = x;
+                float x = v[r] * p.alpha + bias_n[r] + bias_m;
+                if (p.act == 1) x = gelu_erf(x);
+                x += rv[r];
+                v[r] = (n0 + r < p.N) ? x : 0.f;  // columns [N, n_store) are written as zeros
             }
+            const bool sfull = n0 + 3 < p.n_store;
             if (p.out_f32) {
                 float *crow = (float *)p.C + coffz + (int64_t)m * p.ldc;
-                if (p.vec_ok && n0 + 3 < p.n_store) {
-                    *(f32x4 *)(crow + n0) = (f32x4){v[0], v[1], v[2], v[3]};
+                if (p.vec_ok && sfull) {
+                    *(f32x4 *)(crow + n0) = v;
                 } else {
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
@@ -193,25 +238,22 @@ __global__ __launch_bounds__(256) void gemm_nt_128(const GemmParams p) {
                 }
             } else {
                 T *crow = (T *)p.C + coffz + (int64_t)m * p.ldc;
-                if (p.vec_ok && n0 + 3 < p.n_store) {
-                    typename Op<DT>::V4 h = {Op<DT>::from_f32(v[0]), Op<DT>::from_f32(v[1]), Op<DT>::from_f32(v[2]),
-                                             Op<DT>::from_f32(v[3])};
-                    *(typename Op<DT>::V4 *)(crow + n0) = h;
-                    if (p.C_lo) {
-                        typename Op<DT>::V4 l;
+                T *lrow = p.C_lo ? (T *)p.C_lo + coffz + (int64_t)m * p.ldc : nullptr;
+                typename Op<DT>::V4 h, l;
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) l[r] = Op<DT>::from_f32(v[r] - Op<DT>::to_f32(h[r]));
-                        *(typename Op<DT>::V4 *)((T *)p.C_lo + coffz + (int64_t)m * p.ldc + n0) = l;
-                    }
+                for (int r = 0; r < 4; ++r) {
+                    h[r] = Op<DT>::from_f32(v[r]);
+                    l[r] = Op<DT>::from_f32(v[r] - Op<DT>::to_f32(h[r]));
+                }
+                if (p.vec_ok && sfull) {
+                    *(typename Op<DT>::V4 *)(crow + n0) = h;
+                    if (lrow) *(typename Op<DT>::V4 *)(lrow + n0) = l;
                 } else {
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
                         if (n0 + r < p.n_store) {
-                            const T h = Op<DT>::from_f32(v[r]);
-                            crow[n0 + r] = h;
-                            if (p.C_lo)
-                                ((T *)p.C_lo + coffz + (int64_t)m * p.ldc)[n0 + r] =
-                                    Op<DT>::from_f32(v[r] - Op<DT>::to_f32(h));
+                            crow[n0 + r] = h[r];
+                            if (lrow) lrow[n0 + r] = l[r];
                         }
                 }
             }
@@ -260,6 +302,8 @@ int gemm_nt_launch(const pio_gemm_t &g, hipStream_t s) {
     bool vec = (((uintptr_t)g.C) % valign == 0) && ((g.ldc * esz) % valign == 0) && ((g.sCb * esz) % valign == 0) &&
                ((g.sCh * esz) % valign == 0);
     p.vec_ok = vec ? 1 : 0;
+    p.r_vec = (g.R && ((uintptr_t)g.R % 16 == 0) && (g.ldr % 4 == 0) && (g.r_stride_b % 4 == 0)) ? 1 : 0;
+    p.bias_vec = (g.bias && ((uintptr_t)g.bias % 16 == 0)) ? 1 : 0;
 
     dim3 grid((unsigned)(tiles_m * p.tiles_n), (unsigned)g.batch, 1);
     dim3 block(256, 1, 1);

@@ -66,7 +66,7 @@ static inline int launch_status() {
 }
 
 // ---- optional per-launch timing for bench.py (pio_prof_begin / pio_prof_end); off by default ----------
-enum { PROF_GEMM_LINEAR = 0, PROF_GEMM_ATTN = 1, PROF_LAYERNORM = 2, PROF_SOFTMAX = 3, PROF_PACK = 4, PROF_CLASSES = 5 };
+enum { PROF_GEMM_LINEAR = 0, PROF_GEMM_ATTN = 1, PROF_LAYERNORM = 2, PROF_SOFTMAX = 3, PROF_PACK = 4, PROF_FLASH = 5, PROF_CLASSES = 6 };
 struct ProfScope {
     int idx;
     hipStream_t s;
@@ -81,6 +81,10 @@ int layernorm_cast_launch(const pio_tensor3_t &x, const pio_layernorm_t *ln, voi
 int softmax_rows_launch(const float *S, int64_t lds, void *P, void *P_lo, int64_t ldp, int B, int H, int Tq, int Tk,
                         float scale, const uint8_t *kv_mask, const uint8_t *q_mask, const uint8_t *full_mask,
                         const float *bias, int dtype, float *probs_out, hipStream_t s);
+bool flash_supported(int dkp, int dvp);
+int flash_attention_launch(int dtype, int dkp, int dvp, int dk_logical, const void *Q, const void *K, const void *VT,
+                           void *O, int B, int H, int Tq, int Tk, int64_t ldq, int64_t ldk, int64_t ldvt, int64_t ldo,
+                           int64_t sQb, int64_t sKb, int64_t sVb, int64_t sOb, hipStream_t s);
 int pack_linear_launch(const float *w, const float *bias, int out, int in, int64_t ldw, int row_heads,
                        int col_heads, void *dst_hi, void *dst_lo, float *dst_bias, int dst_row0, int k_pad,
                        int dtype, hipStream_t s);

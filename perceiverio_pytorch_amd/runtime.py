@@ -152,6 +152,38 @@ class PackedLinear:
                              self.n, self.k)
 
 
+class PackedStack:
+    """Several nn.Linear with equal in_features stacked along the output rows in ONE packed image
+    (e.g. proj_q | proj_k, consumed by a single GEMM when both read the same input)."""
+
+    def __init__(self, pairs, row_heads: int, dtype: int, two_pass: bool):
+        lib = L.lib()
+        w0 = pairs[0][0]
+        require_device(w0, "pack_linear")
+        dev = w0.device
+        inn = w0.shape[1]
+        self.k = pad8(inn)
+        rows = [row_heads * pad8(w.shape[0] // row_heads) for w, _ in pairs]
+        self.n = sum(rows)
+        tdt = torch.float16 if dtype == L.PIO_DT_F16 else torch.bfloat16
+        self.hi = torch.empty((self.n, self.k), dtype=tdt, device=dev)
+        self.lo = torch.empty((self.n, self.k), dtype=tdt, device=dev) if two_pass else None
+        self.bias = torch.empty((self.n,), dtype=torch.float32, device=dev)
+        r0 = 0
+        for (w, b), nr in zip(pairs, rows):
+            if w.shape[1] != inn:
+                raise ValueError("stacked linears need equal in_features")
+            wf = w.detach().float().contiguous()
+            bf = b.detach().float().contiguous() if b is not None else None
+            L.check(lib.pio_pack_linear(wf.data_ptr(), bf.data_ptr() if bf is not None else None, w.shape[0], inn,
+                                        inn, row_heads, 1, self.hi.data_ptr(),
+                                        self.lo.data_ptr() if two_pass else None, self.bias.data_ptr(), r0, self.k,
+                                        dtype, stream_ptr(dev)), "pio_pack_linear")
+            r0 += nr
+        self.desc = L.Linear(self.hi.data_ptr(), self.lo.data_ptr() if two_pass else None, self.bias.data_ptr(),
+                             self.n, self.k)
+
+
 def param_key(*params) -> tuple:
     """Cache key that changes whenever a parameter is rebound, moved or modified in place."""
     return tuple((p.data_ptr(), p._version, str(p.device)) if p is not None else None for p in params) + (_policy,)

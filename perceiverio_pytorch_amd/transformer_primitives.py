@@ -134,7 +134,13 @@ class Attention(_HipModule):
         d = L.Attention(q.desc, k.desc, v.desc, o.desc, H, dk, dv, R.pad8(dk), R.pad8(dv),
                         self.proj_q.in_features, self.proj_k.in_features, self.proj_v.in_features,
                         self.final.out_features, dtype, int(split))
-        return d, [q, k, v, o]
+        keep = [q, k, v, o]
+        if self.proj_q.in_features == self.proj_k.in_features and not split:
+            qk = R.PackedStack([(self.proj_q.weight, self.proj_q.bias), (self.proj_k.weight, self.proj_k.bias)],
+                               H, dtype, two)
+            d.qk = qk.desc
+            keep.append(qk)
+        return d, keep
 
     def _params(self):
         return (self.proj_q.weight, self.proj_q.bias, self.proj_k.weight, self.proj_k.bias, self.proj_v.weight,

@@ -250,6 +250,53 @@ def test_attention_return_matrix_and_bias(dev):
     assert np.abs(pm.cpu().numpy() - rm).max() <= 1e-5
 
 
+FLASH_CASES = [
+    # heads, dk, dv, B, Tq, Tk   (per-head widths handled by the fused attention kernel; ragged Tq / Tk tails)
+    (8, 128, 128, 2, 512, 512),
+    (2, 128, 128, 1, 100, 777),
+    (8, 64, 64, 2, 784, 784),
+    (16, 32, 32, 1, 2048, 2048),
+    (4, 32, 32, 3, 33, 65),
+    (8, 32, 160, 1, 256, 256),
+    (2, 32, 160, 2, 50, 130),
+]
+
+
+@pytest.mark.parametrize("policy", ["fp16", "fp16x2w", "bf16"])
+@pytest.mark.parametrize("case", FLASH_CASES)
+def test_fused_attention_vs_oracle(dev, case, policy):
+    """Attention.forward on the fused (flash) path against the float64 oracle and against the materialised
+    3-sweep path of the same library."""
+    from perceiverio_pytorch_amd.transformer_primitives import Attention
+    H, dk, dv, B, Tq, Tk = case
+    cin = 96
+    p = O.gen_attention("", cin, cin, H * dk, H * dv, cin, seed=H * dk + Tq)
+    rng = np.random.default_rng(Tk)
+    xq = rng.standard_normal((B, Tq, cin)).astype(np.float32)
+    xkv = rng.standard_normal((B, Tk, cin)).astype(np.float32)
+    m = Attention(cin, cin, cin, num_heads=H, qk_out_channels=H * dk, v_out_channels=H * dv, output_channels=cin)
+    m.load_state_dict(_sd(p, "cpu"))
+    m = m.to(dev).eval()
+    p64 = {k: a.astype(np.float64) for k, a in p.items()}
+    ref = O.attention(p64, xq.astype(np.float64), xkv.astype(np.float64), xkv.astype(np.float64), H)
+    _policy(policy)
+    y = m(_t(xq, dev), _t(xkv, dev), _t(xkv, dev))
+    _assert_close(y, ref, TOL if policy != "bf16" else 1e-2, what=f"fused attention {case} {policy}")
+    # a spiky query row forces large running-max jumps between key tiles (the online-softmax rescale branch);
+    # compare the fused kernel with the materialised-score path of the SAME policy (return_matrix forces it):
+    # identical operand rounding, different algorithm.
+    xs = xq.copy()
+    xs[0, 0] *= 8.0
+    xs[-1, -1] *= -8.0
+    yf = m(_t(xs, dev), _t(xkv, dev), _t(xkv, dev))
+    _, ym = m(_t(xs, dev), _t(xkv, dev), _t(xkv, dev), return_matrix=True)
+    # (the two round P at different points -- un-normalised vs normalised -- so they differ by ~1 ulp16 of P)
+    _assert_close(yf, ym.cpu().numpy(), TOL if policy != "bf16" else 8e-3, what=f"fused vs materialised {case} {policy}")
+    _policy("fp16x3")
+    y3 = m(_t(xq, dev), _t(xkv, dev), _t(xkv, dev))
+    _assert_close(y3, ref, TIGHT, what=f"materialised attention {case}")
+
+
 @pytest.mark.parametrize("policy", POLICIES)
 @pytest.mark.parametrize("name", MLP)
 def test_mlp_golden(dev, name, policy):
