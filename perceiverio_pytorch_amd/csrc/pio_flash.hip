@@ -30,7 +30,7 @@ struct FlashParams {
 static __device__ __attribute__((aligned(16))) uint32_t g_zero_chunk_f[4] = {0, 0, 0, 0};
 
 template <int DT, int DK, int DV>
-__global__ __launch_bounds__(256) void flash_attn_kernel(const FlashParams p) {
+__global__ __launch_bounds__(256, 2) void flash_attn_kernel(const FlashParams p) {  // 2 workgroups per CU
     typedef typename Op<DT>::T T;
     typedef typename Op<DT>::V8 V8;
     typedef typename Op<DT>::V4 V4;
@@ -162,10 +162,14 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const FlashParams p) {
                 psum += e;
             }
         l_run = l_run * alpha + psum;
+        // rescale the output accumulators only when some row's running max actually moved (alpha == 1
+        // exactly otherwise): after the first few tiles this is rare and saves NDT*16 multiplies per tile
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
 #pragma unroll
-        for (int d = 0; d < NDT; ++d)
+            for (int d = 0; d < NDT; ++d)
 #pragma unroll
-            for (int j = 0; j < 16; ++j) oacc[d][j] *= alpha;
+                for (int j = 0; j < 16; ++j) oacc[d][j] *= alpha;
+        }
 
         // ---- P^T fragments: registers 8s..8s+7 of the S^T accumulator are the B operand of k-step s
         V8 pf[2][2];
