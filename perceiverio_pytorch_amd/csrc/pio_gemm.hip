@@ -14,52 +14,14 @@
 //     columns of one row: bias / residual / stores are 8- or 16-byte vectors;
 //   * optional second K sweep with one operand replaced by its *_lo image (W = W_hi + W_lo, the "x2w"
 //     precision policy) accumulating into the same registers.
-#include "pio_internal.h"
+#include "pio_gemm_common.h"
 
 namespace pio {
 
 __device__ __attribute__((aligned(16))) uint32_t g_zero_chunk[4] = {0, 0, 0, 0};
 
-struct GemmParams {
-    const void *A, *B;
-    int64_t dA1, dB1, dA2, dB2;  // element offsets of the pass-1 / pass-2 operands relative to A / B
-    int npass;                   // 1..3 K sweeps accumulating into the same registers
-    void *C, *C_lo;
-    int M, N, K;
-    int64_t lda, ldb, ldc;
-    int nh;
-    int64_t sAb, sAh, sBb, sBh, sCb, sCh;
-    const float *bias;
-    int bias_mode, act;
-    float alpha;
-    const float *R;
-    int64_t ldr, r_stride_b;
-    int r_rows;
-    int out_f32, n_store;
-    int tiles_n;
-    int vec_ok;    // C rows are 16-byte (fp32) / 8-byte (16-bit) aligned for 4-column vectors
-    int r_vec;     // residual rows are 16-byte aligned
-    int bias_vec;  // bias is 16-byte aligned
-};
-
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand tile
-
-// erf by Abramowitz & Stegun 7.1.26 (|abs error| <= 1.5e-7, i.e. fp32-level for GELU): one v_exp, one v_rcp and
-// a 5-term polynomial instead of libm's branchy erff (which cost ~20 % of a K=1024 GEMM's time in the epilogue).
-__device__ __forceinline__ float fast_erf(float x) {
-    const float ax = fabsf(x);
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
-    float poly = fmaf(1.061405429f, t, -1.453152027f);
-    poly = fmaf(poly, t, 1.421413741f);
-    poly = fmaf(poly, t, -0.284496736f);
-    poly = fmaf(poly, t, 0.254829592f);
-    poly *= t;
-    const float e = __builtin_amdgcn_exp2f(-ax * ax * 1.4426950408889634f);
-    const float r = 1.0f - poly * e;
-    return copysignf(r, x);
-}
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752440f)); }
 
 // KIND only tags the instantiation (0: one flat [rows,K]x[N,K] linear, 1: batched attention product) so that
 // profilers report the two uses under different kernel names.
@@ -313,6 +275,24 @@ int gemm_nt_launch(const pio_gemm_t &g, hipStream_t s) {
                    2.0 * elems + (double)g.batch * g.M * g.N * (g.out_f32 ? 4.0 : 2.0) +
                        (g.R ? 4.0 * g.M * g.N * g.batch : 0.0),
                    s);
+    // Large problems go to the 256x256-tile / 4-slot-ring kernel: enough rows, and an N that fills whole
+    // 256-column tiles reasonably (<= 25 % padding).  PIO_GEMM_TILE=128|256 forces one (benchmarks).
+    {
+        static const int forced = [] {
+            const char *e = getenv("PIO_GEMM_TILE");
+            return e ? atoi(e) : 0;
+        }();
+        const int tn256 = (p.n_store + 255) / 256, tm256 = (g.M + 255) / 256;
+        bool big = g.batch == 1 && g.M >= 1024 && p.n_store >= 256 && (double)tn256 * 256.0 <= 1.25 * p.n_store &&
+                   (int64_t)tm256 * tn256 >= 128;
+        if (forced == 128) big = false;
+        if (forced == 256) big = true;
+        if (big) {
+            p.tiles_n = tn256;
+            gemm256_launch(p, g.dtype, attn, tm256, tn256, g.batch, s);
+            return launch_status();
+        }
+    }
     if (g.dtype == PIO_DT_F16) {
         if (attn) hipLaunchKernelGGL((gemm_nt_128<PIO_DT_F16, 1>), grid, block, 0, s, p);
         else      hipLaunchKernelGGL((gemm_nt_128<PIO_DT_F16, 0>), grid, block, 0, s, p);

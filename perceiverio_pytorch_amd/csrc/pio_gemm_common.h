@@ -1,0 +1,125 @@
+// Shared by the two NT-GEMM kernels (pio_gemm.hip: 128x128 tile; pio_gemm256.hip: 256x256 tile).
+#pragma once
+#include "pio_internal.h"
+
+namespace pio {
+
+struct GemmParams {
+    const void *A, *B;
+    int64_t dA1, dB1, dA2, dB2;  // element offsets of the pass-1 / pass-2 operands relative to A / B
+    int npass;                   // 1..3 K sweeps accumulating into the same registers
+    void *C, *C_lo;
+    int M, N, K;
+    int64_t lda, ldb, ldc;
+    int nh;
+    int64_t sAb, sAh, sBb, sBh, sCb, sCh;
+    const float *bias;
+    int bias_mode, act;
+    float alpha;
+    const float *R;
+    int64_t ldr, r_stride_b;
+    int r_rows;
+    int out_f32, n_store;
+    int tiles_n;
+    int vec_ok;    // C rows are 16-byte (fp32) / 8-byte (16-bit) aligned for 4-column vectors
+    int r_vec;     // residual rows are 16-byte aligned
+    int bias_vec;  // bias is 16-byte aligned
+};
+
+
+// erf by Abramowitz & Stegun 7.1.26 (|abs error| <= 1.5e-7, i.e. fp32-level for GELU): one v_exp, one v_rcp and
+// a 5-term polynomial instead of libm's branchy erff (which cost ~20 % of a K=1024 GEMM's time in the epilogue).
+__device__ __forceinline__ float fast_erf(float x) {
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+    float poly = fmaf(1.061405429f, t, -1.453152027f);
+    poly = fmaf(poly, t, 1.421413741f);
+    poly = fmaf(poly, t, -0.284496736f);
+    poly = fmaf(poly, t, 0.254829592f);
+    poly *= t;
+    const float e = __builtin_amdgcn_exp2f(-ax * ax * 1.4426950408889634f);
+    const float r = 1.0f - poly * e;
+    return copysignf(r, x);
+}
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752440f)); }
+
+
+// bias / activation / residual / store of 4 consecutive output columns (m, n0..n0+3) held in v.
+template <int DT>
+__device__ __forceinline__ void epilogue_store4(const GemmParams &p, int64_t coffz, int m, int n0, f32x4 v,
+                                                f32x4 bias_n) {
+    typedef typename Op<DT>::T T;
+    const bool nfull = n0 + 3 < p.N;
+    const float bias_m = (p.bias_mode == 2) ? p.bias[m] : 0.f;
+    f32x4 rv = {0.f, 0.f, 0.f, 0.f};
+    if (p.R) {
+        const float *rrow = (p.r_rows > 0)
+                                ? p.R + (int64_t)(m / p.r_rows) * p.r_stride_b + (int64_t)(m % p.r_rows) * p.ldr
+                                : p.R + (int64_t)m * p.ldr;
+        if (nfull && p.r_vec) {
+            rv = *(const f32x4 *)(rrow + n0);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (n0 + r < p.N) rv[r] = rrow[n0 + r];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float x = v[r] * p.alpha + bias_n[r] + bias_m;
+        if (p.act == 1) x = gelu_erf(x);
+        x += rv[r];
+        v[r] = (n0 + r < p.N) ? x : 0.f;  // columns [N, n_store) are written as zeros
+    }
+    const bool sfull = n0 + 3 < p.n_store;
+    if (p.out_f32) {
+        float *crow = (float *)p.C + coffz + (int64_t)m * p.ldc;
+        if (p.vec_ok && sfull) {
+            *(f32x4 *)(crow + n0) = v;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (n0 + r < p.n_store) crow[n0 + r] = v[r];
+        }
+    } else {
+        T *crow = (T *)p.C + coffz + (int64_t)m * p.ldc;
+        T *lrow = p.C_lo ? (T *)p.C_lo + coffz + (int64_t)m * p.ldc : nullptr;
+        typename Op<DT>::V4 h, l;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            h[r] = Op<DT>::from_f32(v[r]);
+            l[r] = Op<DT>::from_f32(v[r] - Op<DT>::to_f32(h[r]));
+        }
+        if (p.vec_ok && sfull) {
+            *(typename Op<DT>::V4 *)(crow + n0) = h;
+            if (lrow) *(typename Op<DT>::V4 *)(lrow + n0) = l;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (n0 + r < p.n_store) {
+                    crow[n0 + r] = h[r];
+                    if (lrow) lrow[n0 + r] = l[r];
+                }
+        }
+    }
+}
+
+template <int DT>
+__device__ __forceinline__ f32x4 load_bias4(const GemmParams &p, int n0) {
+    f32x4 bias_n = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias_mode == 1) {
+        if (n0 + 3 < p.N && p.bias_vec) {
+            bias_n = *(const f32x4 *)(p.bias + n0);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (n0 + r < p.N) bias_n[r] = p.bias[n0 + r];
+        }
+    }
+    return bias_n;
+}
+
+// 256x256-tile kernel (pio_gemm256.hip); `attn` only selects the kernel-name tag.
+void gemm256_launch(const GemmParams &p, int dtype, bool attn, int tiles_m, int tiles_n, int batch, hipStream_t s);
+
+}  // namespace pio

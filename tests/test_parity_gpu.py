@@ -72,6 +72,12 @@ GEMM_SHAPES = [
     (512, 512, 128, 4, 2, 0, 0, False, True, False),
     (300, 264, 1024, 1, 1, 1, 0, True, True, True),       # two-pass weights
     (1, 8, 8, 1, 1, 1, 0, False, True, False),            # degenerate
+    # shapes routed to the 256x256-tile / 4-slot-ring kernel (M >= 1024, N >= 256)
+    (2048, 1024, 1024, 1, 1, 1, 0, True, True, False),    # the self-attend projection shape (+ residual)
+    (1100, 520, 328, 1, 1, 1, 1, False, False, False),    # ragged M / N / K tails, GELU, 16-bit out
+    (1030, 1000, 72, 1, 1, 1, 0, True, True, True),       # fp32 ldc=1000, residual, two-pass weights, K=72
+    (1024, 256, 40, 2, 1, 2, 0, False, True, False),      # batched, per-row bias, K < one ring (2 K tiles)
+    (4096, 512, 1024, 1, 1, 1, 0, False, False, False),
 ]
 
 

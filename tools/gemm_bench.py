@@ -42,7 +42,10 @@ def run(M, N, K, out_f32, resid, act, lo=False, iters=30, batch=1):
     print(f"M={M} N={N} K={K} b={batch} f32={out_f32} R={resid} act={act} lo={lo}: {us:8.1f} us  {tf:7.1f} TF/s", flush=True)
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and len(sys.argv) > 1:
+    M, N, K = (int(v) for v in sys.argv[1:4])
+    run(M, N, K, False, False, 0, iters=int(sys.argv[4]) if len(sys.argv) > 4 else 10)
+elif __name__ == "__main__":
     run(16384, 1024, 1024, False, False, 0)
     run(16384, 1024, 1024, True, True, 0)
     run(16384, 1024, 1024, False, False, 1)
