@@ -141,7 +141,8 @@ def main():
         y = forward(enc, dec, qtab, x)
         logits = y[:, 0, :]                                   # ClassificationPostprocessor keeps query row 0
         if world > 1:
-            dist.all_gather(gathered, logits.contiguous())    # the path's only collective (RCCL over xGMI)
+            dist.all_gather(gathered, logits.contiguous())    # the path's only collective (RCCL over xGMI);
+            # same call as perceiverio_pytorch_amd.dist.all_gather_rows, with the receive list pre-allocated
         return logits
 
     def sync():

@@ -1,0 +1,50 @@
+"""Data-parallel plumbing for the hot path (one process per GPU, torch.distributed; backend "nccl" is RCCL on ROCm).
+
+Every sample is independent end to end, so the batch is sharded over ranks with replicated
+weights and NO collective on the data path; the only exchange is an all-gather of the per-rank logits
+[B/W, classes] (16 KiB per rank at B=32, W=8: latency-bound over xGMI).  `gloo` is used by the CPU tests."""
+from __future__ import annotations
+
+from typing import List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(total: int, rank: int, world: int) -> Tuple[int, int]:
+    """[lo, hi) of the contiguous shard owned by `rank`; the first (total % world) ranks get one extra item."""
+    if world <= 0 or not (0 <= rank < world):
+        raise ValueError(f"bad rank/world {rank}/{world}")
+    base, extra = divmod(total, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def shard_batch(x: torch.Tensor, rank: Optional[int] = None, world: Optional[int] = None) -> torch.Tensor:
+    """This rank's slice of a [B, ...] tensor (a view)."""
+    if world is None:
+        world = dist.get_world_size() if dist.is_initialized() else 1
+    if rank is None:
+        rank = dist.get_rank() if dist.is_initialized() else 0
+    lo, hi = shard_bounds(x.shape[0], rank, world)
+    return x[lo:hi]
+
+
+def all_gather_rows(local: torch.Tensor, total_rows: Optional[int] = None, group=None) -> torch.Tensor:
+    """Concatenate every rank's [b_r, ...] block along dim 0 in rank order.  Equal shards use one all_gather;
+    ragged shards (total_rows given, not divisible) are padded to the largest shard and trimmed."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return local
+    world = dist.get_world_size(group)
+    local = local.contiguous()
+    if total_rows is None or total_rows % world == 0:
+        out: List[torch.Tensor] = [torch.empty_like(local) for _ in range(world)]
+        dist.all_gather(out, local, group=group)
+        return torch.cat(out, dim=0)
+    sizes = [shard_bounds(total_rows, r, world) for r in range(world)]
+    mx = max(hi - lo for lo, hi in sizes)
+    pad = torch.zeros((mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    out = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(out, pad, group=group)
+    return torch.cat([o[: hi - lo] for o, (lo, hi) in zip(out, sizes)], dim=0)

@@ -1,0 +1,61 @@
+"""CPU, world_size 2 over gloo: the batch sharding and the all-gather of logits used by bench.py --gpus N."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, total, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from perceiverio_pytorch_amd.dist import all_gather_rows, shard_batch
+    full = torch.arange(total * 5, dtype=torch.float32).reshape(total, 5)
+    mine = shard_batch(full)                      # every sample is independent: a rank computes only its rows
+    logits = mine * 2.0 + 1.0                     # stand-in for the per-rank forward
+    out = all_gather_rows(logits, total_rows=total)
+    q.put((rank, mine.shape[0], out.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("total", [32, 7])
+def test_shard_and_allgather_world2(total):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, total, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    full = np.arange(total * 5, dtype=np.float32).reshape(total, 5) * 2.0 + 1.0
+    assert sum(r[1] for r in res) == total
+    for _, _, out in res:
+        assert np.array_equal(out, full)          # rank order preserved, ragged shard trimmed
+
+
+def test_shard_bounds_cover_exactly():
+    from perceiverio_pytorch_amd.dist import shard_bounds
+    for total in (1, 7, 32, 33):
+        for world in (1, 2, 4, 8):
+            spans = [shard_bounds(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+    with pytest.raises(ValueError):
+        shard_bounds(4, 2, 2)

@@ -1,0 +1,97 @@
+"""CPU: the nn.Module mirror keeps the reference's constructor surface, state_dict names and error behaviour;
+the product path refuses to compute without the GPU (no fallback)."""
+import numpy as np
+import pytest
+import torch
+
+import perceiver_oracle as O
+from cases import ENCDEC_CASES, gen_encdec_inputs
+from _golden import load, params
+
+
+def test_state_dict_names_and_shapes_match_reference_goldens():
+    from perceiverio_pytorch_amd.transformer_primitives import Attention, CrossAttention, MLP, SelfAttention
+    g = load("attn_h8_lang_dims")
+    B, Tq, Tk, q_in, kv_in, H, qk, v, out = (int(x) for x in g["meta"])
+    m = Attention(q_in, kv_in, kv_in, num_heads=H, qk_out_channels=qk, v_out_channels=v, output_channels=out)
+    m.load_state_dict({k: torch.from_numpy(a) for k, a in params(g).items()}, strict=True)
+    g = load("sa_w4_h2")
+    B, N, D, H, w = (int(x) for x in g["meta"])
+    SelfAttention(D, widening_factor=w, num_heads=H).load_state_dict(
+        {k: torch.from_numpy(a) for k, a in params(g).items()}, strict=True)
+    g = load("ca_noresid_q")
+    B, Tq, Tk, q_in, kv_in, H, resid, kv = (int(x) for x in g["meta"])
+    CrossAttention(q_in, kv_in, num_heads=H, shape_for_attn="q", use_query_residual=False).load_state_dict(
+        {k: torch.from_numpy(a) for k, a in params(g).items()}, strict=True)
+    g = load("mlp_w4")
+    MLP(int(g["meta"][0]), widening_factor=int(g["meta"][1])).load_state_dict(
+        {k: torch.from_numpy(a) for k, a in params(g).items()}, strict=True)
+
+
+def test_encoder_decoder_state_dict_matches_generator_names():
+    from perceiverio_pytorch_amd.perceiver import PerceiverDecoder, PerceiverEncoder
+    cfg = ENCDEC_CASES["encdec_tiny_masked"]
+    p_enc, p_dec, *_ = gen_encdec_inputs("x", cfg, 1)
+    enc = PerceiverEncoder(cfg["C"], cfg["L"], cfg["blocks"], cfg["N"], cfg["D"], qk_channels=cfg["qk"],
+                           v_channels=cfg["v"], num_cross_attend_heads=cfg["xh"], num_self_attend_heads=cfg["sh"])
+    dec = PerceiverDecoder(cfg["Dq"], cfg["Dq"], cfg["D"], qk_channels=cfg["dqk"], v_channels=cfg["dv"],
+                           num_heads=cfg["dh"], final_project=False)
+    assert sorted(enc.state_dict()) == sorted(p_enc)
+    assert sorted(dec.state_dict()) == sorted(p_dec)
+    for k, v in enc.state_dict().items():
+        assert tuple(v.shape) == p_enc[k].shape, k
+    lat = enc.latents(torch.zeros(5, 3, cfg["C"]))
+    assert lat.shape == (5, cfg["N"], cfg["D"]) and lat.stride(0) == 0      # broadcast view, like the reference
+
+
+def test_constructor_errors_follow_the_reference():
+    from perceiverio_pytorch_amd.perceiver import PerceiverDecoder, PerceiverEncoder
+    from perceiverio_pytorch_amd.transformer_primitives import Attention, CrossAttention
+    with pytest.raises(ValueError, match="qk_out_channels"):
+        Attention(30, 30, 30, num_heads=8)                      # transformer_primitives.py:66-68
+    with pytest.raises(ValueError, match="v_channels"):
+        Attention(32, 32, 32, num_heads=8, v_out_channels=36)   # :69-71
+    with pytest.raises(TypeError):
+        Attention(8)                                            # k_in_channels=None reaches nn.Linear
+    with pytest.raises(ValueError, match="shape_for_attention"):
+        CrossAttention(8, 8, shape_for_attn="x")                # :342
+    with pytest.raises(ValueError, match="num_self_attend_heads"):
+        PerceiverEncoder(8, num_latent_channels=30)             # perceiver.py:54-56
+    with pytest.raises(ValueError, match="output_w_init"):
+        PerceiverDecoder(8, 8, output_w_init="ones")            # perceiver.py:163
+
+
+def test_no_cpu_fallback():
+    from perceiverio_pytorch_amd import PioError
+    from perceiverio_pytorch_amd.transformer_primitives import MLP, SelfAttention
+    with pytest.raises(PioError, match="no CPU or eager fallback"):
+        SelfAttention(16, num_heads=2)(torch.zeros(1, 4, 16))
+    with pytest.raises(PioError):
+        MLP(16)(torch.zeros(1, 4, 16))
+
+
+def test_product_package_never_imports_the_oracle():
+    import os
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "perceiverio_pytorch_amd")
+    for dp, _, files in os.walk(root):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dp, f)).read()
+                assert "perceiver_oracle" not in src and "import oracle" not in src and "from oracle" not in src, f
+
+
+def test_precision_policy_switch():
+    import perceiverio_pytorch_amd as P
+    old = P.get_precision_policy()
+    P.set_precision_policy("fp16x2w")
+    assert P.get_precision_policy() == "fp16x2w"
+    with pytest.raises(ValueError):
+        P.set_precision_policy("fp8")
+    P.set_precision_policy(old)
+
+
+def test_mask_helper_matches_oracle():
+    from perceiverio_pytorch_amd.transformer_primitives import make_cross_attention_mask
+    g = load("mask")
+    m = make_cross_attention_mask(torch.from_numpy(g["query_mask"]), torch.from_numpy(g["kv_mask"]))
+    assert m.dtype == torch.bool and np.array_equal(m.numpy(), g["mask"])

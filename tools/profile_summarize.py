@@ -1,0 +1,49 @@
+"""Condense rocprofv3 output of tools/profile_round.sh into small, commit-able summaries."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+out, tag = sys.argv[1], sys.argv[2]
+
+
+def short(name):
+    name = name.replace("void ", "")
+    return name.split("(")[0][:70]
+
+
+res = {"tag": tag}
+stats = glob.glob(f"{out}/trace/*/*kernel_stats.csv")
+rows = []
+if stats:
+    for r in csv.DictReader(open(stats[0])):
+        rows.append({"kernel": short(r["Name"]), "calls": int(r["Calls"]), "total_ms": float(r["TotalDurationNs"]) / 1e6,
+                     "avg_us": float(r["AverageNs"]) / 1e3, "pct": float(r["Percentage"])})
+res["kernel_stats"] = rows[:12]
+for key, cname in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+    f = glob.glob(f"{out}/pmc_{key}/*/*counter_collection.csv")
+    agg = collections.defaultdict(lambda: [0.0, 0])
+    if f:
+        for r in csv.DictReader(open(f[0])):
+            if r["Counter_Name"] == cname:
+                a = agg[short(r["Kernel_Name"])]
+                a[0] += float(r["Counter_Value"])
+                a[1] += 1
+    res[key] = {k: {"sum_kb": v[0], "launches": v[1], "kb_per_launch": v[0] / max(v[1], 1)} for k, v in agg.items()
+                if k.startswith("pio::")}
+# HBM traffic per launch, gfx950 correction of MI355X_MICROARCH.md (HBM section): FETCH_SIZE reports half of the
+# bytes of wide (16 B/lane) coalesced reads -> x2; WRITE_SIZE is exact; both counters are in KiB.
+traffic = {}
+for k in res.get("fetch", {}):
+    fk = res["fetch"][k]["kb_per_launch"]
+    wk = res.get("write", {}).get(k, {}).get("kb_per_launch", 0.0)
+    traffic[k] = {"bytes_per_launch": (2.0 * fk + wk) * 1024.0, "fetch_kb_raw": fk, "write_kb": wk}
+res["traffic"] = traffic
+try:
+    res["bench"] = json.loads(open(f"{out}/bench.json").read().strip().splitlines()[-1])
+except Exception as e:  # noqa: BLE001
+    res["bench"] = {"error": str(e)}
+json.dump(res, open(f"{out}/summary_{tag}.json", "w"), indent=1)
+print(json.dumps({"kernel_stats": res["kernel_stats"][:6], "traffic": traffic}, indent=1)[:3000])
