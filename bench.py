@@ -169,16 +169,18 @@ def main():
         L.check(lib.pio_prof_begin(4096 * nprof), "pio_prof_begin")
         for _ in range(nprof):
             step()
-        ms = (C.c_double * 6)()
-        fl = (C.c_double * 6)()
-        by = (C.c_double * 6)()
-        ln = (C.c_int64 * 6)()
+        NCLS = 7
+        ms = (C.c_double * NCLS)()
+        fl = (C.c_double * NCLS)()
+        by = (C.c_double * NCLS)()
+        ln = (C.c_int64 * NCLS)()
         nrec = lib.pio_prof_end(ms, fl, by, ln)
         assert nrec > 0, nrec
 
     ms_per_step = elapsed / args.steps * 1e3
     value = world * B * args.steps / elapsed
-    names = ["gemm_linear", "gemm_batched", "layernorm_cast", "softmax", "pack", "fused_attention"]
+    names = ["gemm_nt_256", "gemm_nt_128_batched", "layernorm_cast", "softmax", "pack", "flash_attn",
+             "gemm_nt_128_flat"]
     kernels = {}
     for i, nm in enumerate(names):
         if ln[i]:
@@ -186,11 +188,20 @@ def main():
                            "avg_us": ms[i] / ln[i] * 1e3,
                            "algo_tflops": (fl[i] / (ms[i] * 1e-3) / 1e12) if fl[i] else None,
                            "algo_gbps": by[i] / (ms[i] * 1e-3) / 1e9}
-    g = kernels["gemm_linear"]
-    roofline = {"kernel": "pio::gemm_nt_128<f16,0> (linear layers)", "bound": "mfma",
-                "achieved": g["algo_tflops"], "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": g["algo_tflops"] / MFMA_PEAK_TFLOPS, "traffic": None,
-                "avg_launch_us": g["avg_us"], "launches_per_step": g["launches_per_step"]}
+    g = kernels["gemm_nt_256"]
+    # HBM traffic of that kernel per launch: PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes of
+    # this same command, gfx950 correction of MI355X_MICROARCH.md) condensed into profiles/traffic.json
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            traffic = json.load(f)["pio::gemm_nt_256"]["bytes_per_launch"]
+    except Exception:  # noqa: BLE001  (no committed profile yet)
+        traffic = None
+    roofline = {"kernel": "pio::gemm_nt_256 (weight GEMMs of the latent stack: QK / out / fc1 / fc2 projections)",
+                "bound": "mfma", "achieved": g["algo_tflops"], "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": g["algo_tflops"] / MFMA_PEAK_TFLOPS, "traffic": traffic,
+                "avg_launch_us": g["avg_us"], "launches_per_step": g["launches_per_step"],
+                "algo_flops_per_launch": fl[0] / ln[0], "algo_bytes_per_launch": by[0] / ln[0]}
 
     out = {
         "metric": "samples/sec PerceiverIO fwd (ImageNet-224 conv cfg, 512x1024 latents, 8x6 self-attends)",

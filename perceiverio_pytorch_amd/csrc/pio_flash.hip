@@ -21,7 +21,7 @@ namespace pio {
 struct FlashParams {
     const void *Q, *K, *VT;
     void *O;
-    int Tq, Tk, H;
+    int Tq, Tk, H, nqt;
     int64_t ldq, ldk, ldvt, ldo;
     int64_t sQb, sKb, sVb, sOb;  // batch strides (elements); 0 for a batch-invariant Q
     float scale_log2;            // log2(e) / sqrt(dk)
@@ -49,8 +49,14 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const FlashParams p)
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r32 = lane & 31, hh = lane >> 5;
-    const int b = blockIdx.y / p.H, h = blockIdx.y % p.H;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    // 1-D grid, remapped so that the q-tiles of one (batch, head) -- which stream the same K / V^T -- are
+    // consecutive on ONE XCD (ids are dealt round-robin over the 8 XCDs): their K/V re-reads hit that L2.
+    int bid = blockIdx.x;
+    const int nblk = gridDim.x;
+    if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
+    const int qt = bid % p.nqt, bh = bid / p.nqt;
+    const int b = bh / p.H, h = bh % p.H;
+    const int q0 = qt * 128 + wave * 32;
 
     const T *Qg = (const T *)p.Q + b * p.sQb + (int64_t)h * DK;
     const T *Kg = (const T *)p.K + b * p.sKb + (int64_t)h * DK;
@@ -230,13 +236,14 @@ int flash_attention_launch(int dtype, int dkp, int dvp, int dk_logical, const vo
                            int64_t sQb, int64_t sKb, int64_t sVb, int64_t sOb, hipStream_t s) {
     if (!flash_supported(dkp, dvp)) return PIO_E_SHAPE;
     if (!Q || !K || !VT || !O) return PIO_E_ARG;
-    if (B <= 0 || H <= 0 || Tq <= 0 || Tk <= 0 || (int64_t)B * H > 65535) return PIO_E_SHAPE;
+    if (B <= 0 || H <= 0 || Tq <= 0 || Tk <= 0 || (int64_t)B * H * ((Tq + 127) / 128) > 0x7fffffffLL) return PIO_E_SHAPE;
     if ((ldq % 8) || (ldk % 8) || (ldvt % 8) || (ldo % 4) || (sQb % 8) || (sKb % 8) || (sVb % 8) || (sOb % 4))
         return PIO_E_ALIGN;
     if (((uintptr_t)Q & 15) || ((uintptr_t)K & 15) || ((uintptr_t)VT & 15) || ((uintptr_t)O & 7)) return PIO_E_ALIGN;
-    FlashParams p{Q, K, VT, O, Tq, Tk, H, ldq, ldk, ldvt, ldo, sQb, sKb, sVb, sOb,
+    const int nqt = (Tq + 127) / 128;
+    FlashParams p{Q, K, VT, O, Tq, Tk, H, nqt, ldq, ldk, ldvt, ldo, sQb, sKb, sVb, sOb,
                   1.4426950408889634f / sqrtf((float)dk_logical)};
-    dim3 grid((unsigned)((Tq + 127) / 128), (unsigned)(B * H), 1), block(256, 1, 1);
+    dim3 grid((unsigned)(nqt * B * H), 1, 1), block(256, 1, 1);
     ProfScope prof(PROF_FLASH, 2.0 * B * H * (double)Tq * Tk * (dkp + dvp),
                    2.0 * B * H * ((double)Tq * (dkp + dvp) + (double)Tk * (dkp + dvp)), s);
 #define PIO_FLASH(DTV, DKV, DVV) hipLaunchKernelGGL((flash_attn_kernel<DTV, DKV, DVV>), grid, block, 0, s, p)

@@ -271,10 +271,9 @@ int gemm_nt_launch(const pio_gemm_t &g, hipStream_t s) {
     dim3 block(256, 1, 1);
     const bool attn = g.batch > 1;
     const double elems = (double)g.batch * ((double)g.M * g.K + (double)g.N * g.K);
-    ProfScope prof(attn ? PROF_GEMM_ATTN : PROF_GEMM_LINEAR, 2.0 * g.M * g.N * (double)g.K * g.batch,
-                   2.0 * elems + (double)g.batch * g.M * g.N * (g.out_f32 ? 4.0 : 2.0) +
-                       (g.R ? 4.0 * g.M * g.N * g.batch : 0.0),
-                   s);
+    const double algo_flops = 2.0 * g.M * g.N * (double)g.K * g.batch;
+    const double algo_bytes = 2.0 * elems + (double)g.batch * g.M * g.N * (g.out_f32 ? 4.0 : 2.0) +
+                              (g.R ? 4.0 * g.M * g.N * g.batch : 0.0);
     // Large problems go to the 256x256-tile / 4-slot-ring kernel: enough rows, and an N that fills whole
     // 256-column tiles reasonably (<= 25 % padding).  PIO_GEMM_TILE=128|256 forces one (benchmarks).
     {
@@ -288,11 +287,13 @@ int gemm_nt_launch(const pio_gemm_t &g, hipStream_t s) {
         if (forced == 128) big = false;
         if (forced == 256) big = true;
         if (big) {
+            ProfScope prof(PROF_GEMM_LINEAR, algo_flops, algo_bytes, s);  // class 0 == kernel gemm_nt_256
             p.tiles_n = tn256;
             gemm256_launch(p, g.dtype, attn, tm256, tn256, g.batch, s);
             return launch_status();
         }
     }
+    ProfScope prof(attn ? PROF_GEMM_ATTN : PROF_GEMM_SMALL, algo_flops, algo_bytes, s);  // kernel gemm_nt_128
     if (g.dtype == PIO_DT_F16) {
         if (attn) hipLaunchKernelGGL((gemm_nt_128<PIO_DT_F16, 1>), grid, block, 0, s, p);
         else      hipLaunchKernelGGL((gemm_nt_128<PIO_DT_F16, 0>), grid, block, 0, s, p);
