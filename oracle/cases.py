@@ -60,3 +60,76 @@ def encdec_kwargs(cfg, im=None, qm=None):
                 encoder_query_residual=cfg["enc_resid"], decoder_heads=cfg["dh"],
                 decoder_query_residual=cfg["dec_resid"], final_project=cfg["out"] is not None,
                 input_mask=im, query_mask=qm)
+
+
+# ---------------------------------------------------------------------------------------------------
+# whole-model cases ("next" rows of SURVEY.md 8f): parameters for an arbitrary state_dict spec
+# ---------------------------------------------------------------------------------------------------
+def gen_state_dict(spec, seed):
+    """spec: iterable of (name, shape).  Deterministic, non-trivial values for every entry kind that occurs in the
+    reference's models (weights ~ fan-in scaled, biases / LayerNorm / BatchNorm statistics perturbed)."""
+    out = {}
+    for name, shape in spec:
+        shape = tuple(int(s) for s in shape)
+        leaf = name.rsplit(".", 1)[-1]
+        rng = O._rng_for(name, seed)
+        if leaf == "num_batches_tracked":
+            out[name] = np.zeros(shape, dtype=np.int64)
+        elif leaf == "running_mean":
+            out[name] = (0.05 * rng.standard_normal(shape)).astype(np.float32)
+        elif leaf == "running_var":
+            out[name] = (1.0 + 0.2 * np.abs(rng.standard_normal(shape))).astype(np.float32)
+        elif leaf == "pos_embs":
+            out[name] = O.gen_tensor(name, shape, seed, "table") if int(np.prod(shape)) else np.zeros(shape, np.float32)
+        elif leaf == "bias":
+            out[name] = O.gen_tensor(name, shape, seed, "bias")
+        elif leaf == "weight" and len(shape) == 1:
+            out[name] = O.gen_tensor(name, shape, seed, "ln_weight")
+        elif leaf == "weight" and ".embed." in name or name.endswith("_embedding.weight"):
+            out[name] = (0.3 * rng.standard_normal(shape)).astype(np.float32)
+        elif leaf == "weight":
+            fan_in = int(np.prod(shape[1:]))
+            w = np.clip(rng.standard_normal(shape), -2.0, 2.0) / 0.87962566103423978
+            out[name] = (w / np.sqrt(fan_in)).astype(np.float32)
+        else:
+            raise ValueError(f"don't know how to generate {name} {shape}")
+    return out
+
+
+MODEL_CASES = {
+    # name: (class, ctor kwargs, input recipe)
+    "model_classify_conv": dict(cls="ClassificationPerceiver", kw=dict(prep="FOURIER_POS_CONVNET"), batch=2),
+    "model_classify_1x1": dict(cls="ClassificationPerceiver", kw=dict(prep="LEARNED_POS_1X1CONV"), batch=1),
+    "model_classify_pixel": dict(cls="ClassificationPerceiver", kw=dict(prep="FOURIER_POS_PIXEL"), batch=1),
+    "model_language": dict(cls="LanguagePerceiver", kw=dict(), batch=2),
+    "model_flow_small": dict(cls="FlowPerceiver", kw=dict(img_size=(48, 64), num_latents=128, num_latent_channels=128,
+                                                          num_self_attends_per_block=2), batch=1),
+    "model_multimodal_small": dict(cls="MultiModalPerceiver",
+                                   kw=dict(img_size=(16, 16), num_frames=2, num_classes=10,
+                                           audio_samples_per_frame=32, audio_samples_per_patch=16,
+                                           num_self_attends_per_block=1, num_latents=32, num_latent_channels=512),
+                                   batch=2),
+}
+
+
+def model_inputs(name, seed=31):
+    """Seeded inputs of a MODEL_CASES entry as numpy arrays (dict of forward kwargs / positional list)."""
+    c = MODEL_CASES[name]
+    B = c["batch"]
+    if c["cls"] == "ClassificationPerceiver":
+        return [_rand(name + "img", (B, 3, 224, 224), seed)]
+    if c["cls"] == "LanguagePerceiver":
+        rng = np.random.default_rng(seed)
+        tok = rng.integers(6, 262, size=(B, 2048)).astype(np.int64)
+        mask = np.zeros((B, 2048), dtype=bool)
+        for b, n in zip(range(B), (60, 700)):
+            mask[b, :n] = True
+        tok[~mask] = 0
+        return [tok, mask]
+    if c["cls"] == "FlowPerceiver":
+        return [_rand(name + "i1", (B, 3, 60, 80), seed), _rand(name + "i2", (B, 3, 60, 80), seed)]
+    if c["cls"] == "MultiModalPerceiver":
+        kw = c["kw"]
+        return [np.abs(_rand(name + "v", (B, kw["num_frames"], 3) + tuple(kw["img_size"]), seed)),
+                _rand(name + "a", (B, kw["num_frames"] * kw["audio_samples_per_frame"], 1), seed)]
+    raise ValueError(name)

@@ -289,8 +289,8 @@ def case_encdec(only=None):
                   meta=meta_arr, seed=np.array(seed))
 
 
-if __name__ == "__main__":
-    only = set(sys.argv[1:])
+if __name__ == "__main__" and not (sys.argv[1:] and all(a.startswith("model_") for a in sys.argv[1:])):
+    only = set(a for a in sys.argv[1:] if not a.startswith("model_"))
     if not only:
         case_mask()
         case_attention()
@@ -299,3 +299,56 @@ if __name__ == "__main__":
         case_cross_attention()
     case_encdec(only or None)
     print("oracle pinned against the reference; goldens written to", GOLD)
+
+
+# ------------------------------------------------------------------------------------
+# whole models ("next" rows): reference task models with generated parameters -> outputs
+# ------------------------------------------------------------------------------------
+def case_models(only=None):
+    from cases import MODEL_CASES, gen_state_dict, model_inputs
+    from perceiver_io.classification_perceiver import ClassificationPerceiver, PrepType
+    from perceiver_io.flow_perceiver import FlowPerceiver
+    from perceiver_io.language_perceiver import LanguagePerceiver
+    from perceiver_io.multimodal_perceiver import MultiModalPerceiver
+    for name, c in MODEL_CASES.items():
+        if only and name not in only:
+            continue
+        kw = dict(c["kw"])
+        if c["cls"] == "ClassificationPerceiver":
+            model = ClassificationPerceiver(prep_type=PrepType[kw.pop("prep")])
+        else:
+            model = {"LanguagePerceiver": LanguagePerceiver, "FlowPerceiver": FlowPerceiver,
+                     "MultiModalPerceiver": MultiModalPerceiver}[c["cls"]](**kw)
+        sd = model.state_dict()
+        spec = [(k, tuple(v.shape)) for k, v in sd.items()]
+        params = gen_state_dict(spec, 31)
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
+        model.eval()
+        ins = model_inputs(name)
+        tin = [torch.from_numpy(a) for a in ins]
+        save = dict(spec_names=np.array([k for k, _ in spec]),
+                    spec_shapes=np.array([",".join(str(d) for d in s) for _, s in spec]))
+        with torch.inference_mode():
+            if c["cls"] == "FlowPerceiver":
+                out_train = model(tin[0][..., :48, :64], tin[1][..., :48, :64]).numpy()
+                out_test = model(tin[0], tin[1], test_mode=True, min_overlap=10).numpy()
+                save.update(out_train=out_train, out_test=out_test)
+                print(f"{name:42s} train {out_train.shape} test {out_test.shape}")
+            elif c["cls"] == "MultiModalPerceiver":
+                out = model(tin[0], tin[1], n_chunks=2)
+                save.update(out_image=out["image"].numpy(), out_audio=out["audio"].numpy(),
+                            out_label=out["label"].numpy())
+                print(f"{name:42s} image {tuple(out['image'].shape)} audio {tuple(out['audio'].shape)}")
+            elif c["cls"] == "LanguagePerceiver":
+                out = model(tin[0], tin[1]).numpy()
+                save.update(out=out[:, :96], out_tail=out[:, 640:704], out_absmax=np.array(np.abs(out).max()))
+                print(f"{name:42s} logits {out.shape}")
+            else:
+                out = model(tin[0]).numpy()
+                save.update(out=out)
+                print(f"{name:42s} logits {out.shape} absmax {np.abs(out).max():.3f}")
+        _save(name, **save)
+
+
+if __name__ == "__main__" and (not sys.argv[1:] or any(a.startswith("model_") for a in sys.argv[1:])):
+    case_models(set(a for a in sys.argv[1:] if a.startswith("model_")) or None)

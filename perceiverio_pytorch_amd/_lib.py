@@ -11,7 +11,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpio_hip.so")
+LIB_PATH = os.environ.get("PIO_LIB_PATH", os.path.join(_HERE, "libpio_hip.so"))  # override: A/B builds only
 CSRC = os.path.join(_HERE, "csrc")
 
 PIO_DT_F16 = 0

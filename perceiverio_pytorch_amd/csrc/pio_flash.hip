@@ -141,20 +141,23 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const FlashParams p)
         }
         // ---- scale to base 2, mask keys past Tk (last tile only), tile max
         const bool tail = (kt == ntiles - 1) && (p.Tk % KT != 0);
+        // The max is taken on the RAW scores (scale > 0 commutes with max); the scale and the max subtraction are
+        // then one FMA per element:  p = exp2(s * c - m * c).
         float mx = -INFINITY;
+        if (tail) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int key = kt * KT + 32 * t + (i & 3) + 8 * (i >> 2) + 4 * hh;
+                    if (key >= p.Tk) sacc[t][i] = -INFINITY;
+                }
+        }
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                float v = sacc[t][i] * p.scale_log2;
-                if (tail) {
-                    const int key = kt * KT + 32 * t + (i & 3) + 8 * (i >> 2) + 4 * hh;
-                    if (key >= p.Tk) v = -INFINITY;
-                }
-                sacc[t][i] = v;
-                mx = fmaxf(mx, v);
-            }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            for (int i = 0; i < 16; ++i) mx = fmaxf(mx, sacc[t][i]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * p.scale_log2;
         const float m_new = fmaxf(m_run, mx);
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);  // first tile: exp2(-inf) = 0
         m_run = m_new;
@@ -163,7 +166,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const FlashParams p)
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const float e = __builtin_amdgcn_exp2f(sacc[t][i] - m_new);
+                const float e = __builtin_amdgcn_exp2f(fmaf(sacc[t][i], p.scale_log2, -m_new));
                 sacc[t][i] = e;
                 psum += e;
             }

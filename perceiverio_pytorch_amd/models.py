@@ -1,0 +1,241 @@
+"""The four task models of the reference, assembled from the HIP-backed PerceiverIO core and the torch I/O plumbing:
+ClassificationPerceiver (classification_perceiver.py), LanguagePerceiver (language_perceiver.py), FlowPerceiver
+(flow_perceiver.py), MultiModalPerceiver (multimodal_perceiver.py).  Same constructor arguments, `self.perceiver`
+attribute and state_dict keys, so `load_state_dict(ckpt["model_state_dict"])` of a reference checkpoint works."""
+from __future__ import annotations
+
+import itertools
+from enum import Enum
+from typing import Sequence
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .io_processors import (AudioPostprocessor, AudioPreprocessor, ClassificationPostprocessor,
+                            EmbeddingPostprocessor, EmbeddingPreprocessor, FlowPostprocessor, ImagePreprocessor,
+                            OneHotPreprocessor, ProjectionPostprocessor, patches_for_flow)
+from .output_queries import FlowQuery, FourierQuery, TrainableQuery
+from .perceiver import PerceiverIO
+from .position_encoding import PosEncodingType
+
+
+class PrepType(Enum):
+    FOURIER_POS_CONVNET = 1
+    LEARNED_POS_1X1CONV = 2
+    FOURIER_POS_PIXEL = 3
+
+
+class ClassificationPerceiver(nn.Module):
+    """ImageNet classifier: 512 x 1024 latents, 8 blocks x 6 self-attends, 1000 learned queries (reference
+    classification_perceiver.py:21-131)."""
+
+    def __init__(self, num_classes: int = 1000, img_size: Sequence[int] = (224, 224), img_channels: int = 3,
+                 prep_type: PrepType = PrepType.FOURIER_POS_CONVNET, num_self_attends_per_block: int = 6,
+                 num_blocks: int = 8, num_latents: int = 512, num_latent_channels: int = 1024):
+        super().__init__()
+        fourier = dict(concat_pos=True, num_bands=64, sine_only=False)
+        if prep_type == PrepType.FOURIER_POS_CONVNET:
+            prep = ImagePreprocessor(img_size=img_size, input_channels=img_channels, prep_type="conv",
+                                     position_encoding_type=PosEncodingType.FOURIER,
+                                     fourier_position_encoding_kwargs=dict(max_resolution=(56, 56), **fourier))
+        elif prep_type == PrepType.LEARNED_POS_1X1CONV:
+            prep = ImagePreprocessor(img_size=img_size, input_channels=img_channels, prep_type="conv1x1",
+                                     position_encoding_type=PosEncodingType.TRAINABLE,
+                                     trainable_position_encoding_kwargs=dict(init_scale=0.02, num_channels=256),
+                                     project_pos_dim=256, num_channels=256, spatial_downsample=1,
+                                     concat_or_add_pos="concat")
+        elif prep_type == PrepType.FOURIER_POS_PIXEL:
+            prep = ImagePreprocessor(img_size=img_size, input_channels=img_channels, prep_type="pixels",
+                                     spatial_downsample=1, position_encoding_type=PosEncodingType.FOURIER,
+                                     fourier_position_encoding_kwargs=dict(max_resolution=(224, 224), **fourier))
+        else:
+            raise ValueError(f"Unknown prep_type type: {prep_type}")
+        self.perceiver = PerceiverIO(
+            num_blocks=num_blocks, num_self_attends_per_block=num_self_attends_per_block, num_latents=num_latents,
+            num_latent_channels=num_latent_channels, input_preprocessors=prep,
+            perceiver_encoder_kwargs=dict(num_self_attend_heads=8, use_query_residual=True),
+            output_queries=TrainableQuery(output_index_dims=num_classes, num_channels=1024, init_scale=0.02),
+            perceiver_decoder_kwargs=dict(use_query_residual=prep_type != PrepType.LEARNED_POS_1X1CONV),
+            final_project_out_channels=num_classes,
+            output_postprocessors=ClassificationPostprocessor(num_classes=num_classes, num_input_channels=num_classes,
+                                                              project=False))
+
+    def forward(self, img: torch.Tensor):
+        """img: (batch, channels, H, W) -> logits (batch, num_classes)."""
+        return self.perceiver(img)
+
+
+class LanguagePerceiver(nn.Module):
+    """Byte-level masked language model: 256 x 1280 latents, 26 self-attends (reference language_perceiver.py:10-74)."""
+
+    def __init__(self, vocab_size: int = 262, max_seq_len: int = 2048, embed_dim: int = 768,
+                 num_self_attends_per_block: int = 26, num_blocks: int = 1, num_latents: int = 256,
+                 num_latent_channels: int = 1280):
+        super().__init__()
+        prep = EmbeddingPreprocessor(vocab_size=vocab_size, max_seq_len=max_seq_len, embedding_dims=embed_dim)
+        self.perceiver = PerceiverIO(
+            final_project=False, num_self_attends_per_block=num_self_attends_per_block, num_blocks=num_blocks,
+            num_latents=num_latents, num_latent_channels=num_latent_channels, input_preprocessors=prep,
+            output_postprocessors=EmbeddingPostprocessor(prep.embed),
+            perceiver_encoder_kwargs=dict(num_self_attend_heads=8, num_cross_attend_heads=8, qk_channels=8 * 32,
+                                          v_channels=num_latent_channels, use_query_residual=True),
+            perceiver_decoder_kwargs=dict(qk_channels=8 * 32, v_channels=embed_dim, num_heads=8,
+                                          use_query_residual=False),
+            output_queries=TrainableQuery(output_index_dims=max_seq_len, num_channels=embed_dim))
+
+    def forward(self, inputs: torch.Tensor, input_masks: torch.Tensor):
+        return self.perceiver(inputs, input_mask=input_masks, query_mask=input_masks)
+
+
+class FlowPerceiver(nn.Module):
+    """Optical flow: 3x3 patches of a frame pair in, dense per-pixel queries out (reference flow_perceiver.py:20-199)."""
+
+    def __init__(self, img_size: Sequence[int] = (368, 496), flow_scale_factor: int = 20 / 100,
+                 num_latents: int = 2048, num_latent_channels=512, num_self_attends_per_block: int = 24,
+                 num_blocks: int = 1, mixed_precision: bool = False):
+        super().__init__()
+        self._flow_scale_factor = flow_scale_factor
+        self.mixed_precision = mixed_precision    # kept for signature parity: precision is set by the policy here
+        prep = ImagePreprocessor(img_size=img_size, input_channels=3 * 3 ** 2, prep_type="patches",
+                                 spatial_downsample=1, temporal_downsample=2, conv_after_patching=True,
+                                 num_channels=64, n_extra_pos_mlp=0, position_encoding_type=PosEncodingType.FOURIER,
+                                 fourier_position_encoding_kwargs=dict(num_bands=64, max_resolution=img_size,
+                                                                       sine_only=False, concat_pos=True))
+        self.perceiver = PerceiverIO(
+            final_project_out_channels=2, num_blocks=num_blocks,
+            num_self_attends_per_block=num_self_attends_per_block, num_latents=num_latents,
+            num_latent_channels=num_latent_channels, perceiver_encoder_kwargs=dict(num_self_attend_heads=16),
+            perceiver_decoder_kwargs=dict(output_w_init="zeros"),
+            output_queries=FlowQuery(preprocessed_input_channels=prep.n_output_channels(), output_img_size=img_size,
+                                     output_num_channels=2),
+            input_preprocessors=prep,
+            output_postprocessors=FlowPostprocessor(img_size=img_size, flow_scale_factor=flow_scale_factor))
+        self.H, self.W = (img_size, img_size) if isinstance(img_size, int) else tuple(img_size)
+
+    def compute_grid_indices(self, image_shape: tuple, min_overlap: int):
+        """Top-left corners of training-size tiles covering the image with at least ``min_overlap`` overlap."""
+        if min_overlap >= self.H or min_overlap >= self.W:
+            raise ValueError(f"Overlap should be less than size of patch (got {min_overlap}"
+                             f"for patch size {(self.H, self.W)}).")
+        ys = list(range(0, image_shape[0], self.H - min_overlap))
+        xs = list(range(0, image_shape[1], self.W - min_overlap))
+        ys[-1] = image_shape[0] - self.H
+        xs[-1] = image_shape[1] - self.W
+        if image_shape[0] == self.H:
+            ys = [0]
+        if image_shape[1] == self.W:
+            xs = [0]
+        return itertools.product(ys, xs)
+
+    def _predict_patch(self, patch):
+        return self.perceiver(patches_for_flow(patch).movedim(-1, -3))
+
+    def forward(self, image1: torch.Tensor, image2: torch.Tensor, test_mode: bool = False, min_overlap: int = 20):
+        h, w = image1.shape[2], image1.shape[3]
+        pair = torch.stack([image1.contiguous(), image2.contiguous()], dim=1)
+        if h < self.H:
+            raise ValueError(f"Height of image (shape: {image1.shape}) must be at least {self.H:}."
+                             "Please pad or resize your image to the minimum dimension.")
+        if w < self.W:
+            raise ValueError(f"Width of image (shape: {image1.shape}) must be at least {self.W}."
+                             "Please pad or resize your image to the minimum dimension.")
+        if not test_mode:
+            assert h == self.H and w == self.W, \
+                f"In training mode images must have size equal to specified img_size {(self.H, self.W)}"
+            return self._predict_patch(pair)
+        # tiled inference: every tile's flow is blended with a linear ramp that peaks at the tile centre
+        yy, xx = torch.meshgrid(torch.arange(self.H), torch.arange(self.W), indexing="ij")
+        ramp = torch.minimum(torch.minimum(xx + 1, self.W - xx), torch.minimum(yy + 1, self.H - yy))
+        ramp = (ramp / ramp.max())[None, None].to(image1.device)
+        total, weight = 0, 0
+        for y, x in self.compute_grid_indices((h, w), min_overlap):
+            flow = self._predict_patch(pair[..., y:y + self.H, x:x + self.W])
+            pad = (x, w - x - self.W, y, h - y - self.H)
+            total = total + F.pad(flow * ramp, pad)
+            weight = weight + F.pad(ramp, pad)
+        return total / weight
+
+
+class MultiModalPerceiver(nn.Module):
+    """Video + audio + label auto-encoder (reference multimodal_perceiver.py:12-167).  The output is decoded in
+    ``n_chunks`` query chunks.  The encoder input does not depend on the chunk (mask probabilities are 0 / 0 / 1), so
+    by default the preprocess + encode step runs ONCE and only the decoder runs per chunk (`encode_once=False`
+    restores the reference's recompute-everything loop; the results are identical)."""
+
+    def __init__(self, img_size: Sequence[int] = (224, 224), img_channels: int = 3, num_frames: int = 16,
+                 num_classes: int = 700, audio_samples_per_frame: int = 48000 // 25,
+                 audio_samples_per_patch: int = 16, num_self_attends_per_block: int = 8, num_blocks: int = 1,
+                 num_latents: int = 28 * 28 * 1, num_latent_channels: int = 512, encode_once: bool = True):
+        super().__init__()
+        self.H, self.W = img_size
+        self.num_classes = num_classes
+        self.audio_samples_per_frame = audio_samples_per_frame
+        self.audio_samples_per_patch = audio_samples_per_patch
+        self.encode_once = encode_once
+        n_audio = num_frames * audio_samples_per_frame
+        vid_res = (num_frames, self.H // 4, self.W // 4)
+        preps = {
+            "audio": AudioPreprocessor(samples_per_batch=n_audio, prep_type="patches",
+                                       samples_per_patch=audio_samples_per_patch, n_extra_pos_mlp=0,
+                                       position_encoding_type=PosEncodingType.FOURIER,
+                                       fourier_position_encoding_kwargs=dict(num_bands=192,
+                                                                             max_resolution=(n_audio,),
+                                                                             sine_only=False, concat_pos=True)),
+            "image": ImagePreprocessor(img_size=(self.H, self.W), input_channels=img_channels, num_frames=num_frames,
+                                       prep_type="patches", spatial_downsample=4, temporal_downsample=1,
+                                       n_extra_pos_mlp=0, position_encoding_type=PosEncodingType.FOURIER,
+                                       fourier_position_encoding_kwargs=dict(num_bands=32, max_resolution=vid_res,
+                                                                             sine_only=False, concat_pos=True)),
+            "label": OneHotPreprocessor(input_channels=num_classes),
+        }
+        posts = {
+            "audio": AudioPostprocessor(in_channels=512, samples_per_patch=audio_samples_per_patch),
+            "image": ProjectionPostprocessor(num_inputs=512, num_outputs=3),
+            "label": ClassificationPostprocessor(num_input_channels=512, num_classes=num_classes),
+        }
+        queries = {
+            "audio": FourierQuery(concat_preprocessed_input=False,
+                                  output_index_dims=(n_audio // audio_samples_per_patch,), num_bands=192,
+                                  max_resolution=(n_audio,), sine_only=False, concat_pos=True),
+            "image": FourierQuery(concat_preprocessed_input=False, output_index_dims=(num_frames, self.H, self.W),
+                                  num_bands=32, max_resolution=vid_res, sine_only=False, concat_pos=True),
+            "label": TrainableQuery(output_index_dims=(1,), concat_preprocessed_input=False, num_channels=1024,
+                                    init_scale=0.02),
+        }
+        self.perceiver = PerceiverIO(
+            num_self_attends_per_block=num_self_attends_per_block, num_blocks=num_blocks, num_latents=num_latents,
+            num_latent_channels=num_latent_channels, input_preprocessors=preps, output_postprocessors=posts,
+            output_queries=queries, input_padding_channels=4, output_query_padding_channels=2,
+            input_mask_probs={"image": 0.0, "audio": 0.0, "label": 1.0})
+
+    def forward(self, images: torch.Tensor, audio: torch.Tensor, n_chunks: int = 128):
+        b, t, c, h, w = images.shape
+        img_chunk = t * h * w // n_chunks
+        aud_chunk = audio.shape[1] // self.audio_samples_per_patch // n_chunks
+        inputs = {"image": images, "audio": audio,
+                  "label": torch.zeros((b, self.num_classes), device=images.device)}
+        P = self.perceiver
+        rec = {"image": [], "audio": [], "label": []}
+        cached = None
+        for k in range(n_chunks):
+            points = {"image": torch.arange(img_chunk * k, img_chunk * (k + 1)),
+                      "audio": torch.arange(aud_chunk * k, aud_chunk * (k + 1)), "label": None}
+            if not self.encode_once:
+                out = P(inputs, subsampled_output_points=points)
+            else:
+                if cached is None:
+                    x, sizes, without_pos = P._multi_preprocessor(inputs, pos=None)
+                    cached = (x, sizes, without_pos, P._encoder(x, P._encoder.latents(x)))
+                x, sizes, without_pos, latents = cached
+                query, qsizes = P.decoder_query(x, sizes, without_pos, subsampled_points=points)
+                from .perceiver import restructure
+                per_mod = restructure(qsizes, P._decoder(query, latents))
+                out = {m: post(per_mod[m], pos=None, modality_sizes=None)
+                       for m, post in P._output_postprocessors.items()}
+            rec["image"].append(out["image"])
+            rec["audio"].append(out["audio"])
+            rec["label"].append(out["label"][:, None])
+        return {"image": torch.cat(rec["image"], dim=1).reshape([b, t, h, w, c]).moveaxis(-1, -3),
+                "audio": torch.cat(rec["audio"], dim=1).reshape(audio.shape),
+                "label": torch.cat(rec["label"], dim=1).mean(dim=1)}

@@ -133,3 +133,167 @@ class PerceiverDecoder(nn.Module):
         L.check(lib.pio_decoder_fwd(cross, fin_ptr, out_ch, R.tensor3(q), R.tensor3(z), qm_ptr, out.data_ptr(),
                                     ws.data_ptr(), ws.numel(), R.stream_ptr(dev)), "pio_decoder_fwd")
         return out
+
+
+# ==================================================================================================
+# Orchestration around the hot path (reference perceiver.py:183-499): plain PyTorch plumbing that keeps the
+# PerceiverIO constructor surface and state_dict layout.  Modalities are always handled in sorted-key order.
+# ==================================================================================================
+def restructure(modality_sizes, inputs: torch.Tensor):
+    """Split a [B, N, C] array back into per-modality views, in sorted modality order (reference :370-387)."""
+    out, start = {}, 0
+    for name in sorted(modality_sizes.keys()):
+        n = modality_sizes[name]
+        out[name] = inputs[:, start:start + n]
+        start += n
+    return out
+
+
+def _as_module_dict(x):
+    if type(x) is dict:
+        return nn.ModuleDict(x)
+    if isinstance(x, nn.Module) and not isinstance(x, nn.ModuleDict):
+        return nn.ModuleDict({"__default": x})
+    return x
+
+
+class MultimodalPreprocessor(nn.Module):
+    """Runs each modality's preprocessor, pads all of them to a common channel count with learned padding
+    embeddings, optionally replaces tokens by a learned mask token, and concatenates along the index axis
+    (reference :390-499)."""
+
+    def __init__(self, input_preprocessors=None, mask_probs=None, min_padding_size: int = 2, input_channels=None):
+        super().__init__()
+        self._preprocessors = input_preprocessors
+        self._min_padding_size = min_padding_size
+        self._mask_probs = mask_probs
+        if input_preprocessors is not None:
+            assert input_channels is None, "input_channels and modalities are mutually exclusive"
+            input_channels = {m: p.n_output_channels() for m, p in input_preprocessors.items()}
+        else:
+            assert input_channels is not None, "if no preprocessors, input_channels must be specified"
+        self._common_channels = max(input_channels.values()) + min_padding_size
+        if mask_probs is not None:
+            self.mask_tokens = nn.ModuleDict({
+                m: TrainablePositionEncoding(index_dim=1, num_channels=self._common_channels, init_scale=0.02)
+                for m in self._preprocessors.keys()})
+        self.padding_embeddings = None
+        ragged = max(input_channels.values()) != min(input_channels.values())
+        if ragged or min_padding_size != 0:
+            self.padding_embeddings = nn.ModuleDict({
+                m: TrainablePositionEncoding(index_dim=1, num_channels=self._common_channels - p.n_output_channels(),
+                                             init_scale=0.02)
+                for m, p in self._preprocessors.items()})
+
+    def n_output_channels(self):
+        return self._common_channels
+
+    def forward(self, inputs, *, pos=None):
+        if self._preprocessors is None:
+            outputs, without_pos = inputs, inputs
+        else:
+            outputs, without_pos = {}, {}
+            for m, prep in self._preprocessors.items():
+                outputs[m], without_pos[m] = prep(inputs[m], pos=pos)
+        if self.padding_embeddings is not None:
+            padded = {}
+            for m, x in outputs.items():
+                pad = torch.broadcast_to(self.padding_embeddings[m](x.shape[0]),
+                                         [x.shape[0], x.shape[1], self._common_channels - x.shape[2]])
+                padded[m] = torch.cat([x, pad], dim=2)
+            outputs = padded
+        sizes = {m: x.shape[1] for m, x in outputs.items()}
+        if self._mask_probs is not None:
+            masked = {}
+            for m, x in outputs.items():
+                token = self.mask_tokens[m](x.shape[0])
+                p = self._mask_probs[m]
+                if p <= 0.0:
+                    masked[m] = x                              # bernoulli(0) is all zeros: (1-0)*x + 0*token
+                elif p >= 1.0:
+                    masked[m] = torch.broadcast_to(token, x.shape) + 0 * x
+                else:
+                    mask = torch.bernoulli(torch.full([x.shape[0], x.shape[1]], fill_value=float(p))).to(x.device)
+                    mask = mask[:, :, None]
+                    masked[m] = (1 - mask) * x + mask * token
+            outputs = masked
+        ordered = [outputs[m] for m in sorted(outputs.keys())]
+        return torch.cat(ordered, dim=1), sizes, without_pos
+
+
+class PerceiverIO(nn.Module):
+    """preprocess -> PerceiverEncoder -> decoder queries -> PerceiverDecoder -> postprocess (reference :183-367).
+    The encoder / decoder are the HIP-backed modules above; everything else here is batch-invariant table building
+    and tensor bookkeeping in stock torch."""
+
+    def __init__(self, num_blocks: int = 8, num_self_attends_per_block: int = 6, num_latents: int = 512,
+                 num_latent_channels: int = 1024, final_project: bool = True, final_project_out_channels: int = None,
+                 perceiver_encoder_kwargs=None, perceiver_decoder_kwargs=None, input_preprocessors=None,
+                 output_postprocessors=None, output_queries=None, output_query_padding_channels: int = 0,
+                 input_padding_channels: int = 0, input_channels=None, input_mask_probs: dict = None):
+        super().__init__()
+        perceiver_encoder_kwargs = perceiver_encoder_kwargs or {}
+        perceiver_decoder_kwargs = perceiver_decoder_kwargs or {}
+        if final_project_out_channels is None:
+            final_project_out_channels = num_latent_channels
+        if type(input_channels) is int:
+            input_channels = {"__default": input_channels}
+        self._multi_preprocessor = MultimodalPreprocessor(input_preprocessors=_as_module_dict(input_preprocessors),
+                                                          mask_probs=input_mask_probs,
+                                                          min_padding_size=input_padding_channels,
+                                                          input_channels=input_channels)
+        self._output_postprocessors = _as_module_dict(output_postprocessors)
+        self._output_queries = _as_module_dict(output_queries)
+        query_channels = max(q.n_query_channels() for q in self._output_queries.values()) + \
+            output_query_padding_channels
+        self.query_channels = query_channels
+        # every query is padded to the widest one with a learned embedding (width 0 for a single modality:
+        # the (1, 0) parameter still exists in the state_dict, as in the reference)
+        self.padding_embeddings = nn.ModuleDict({
+            m: TrainablePositionEncoding(index_dim=1, num_channels=query_channels - q.n_query_channels(),
+                                         init_scale=0.02)
+            for m, q in self._output_queries.items()})
+        self._encoder = PerceiverEncoder(num_input_channels=self._multi_preprocessor.n_output_channels(),
+                                         num_blocks=num_blocks,
+                                         num_self_attends_per_block=num_self_attends_per_block,
+                                         num_latents=num_latents, num_latent_channels=num_latent_channels,
+                                         **perceiver_encoder_kwargs)
+        self._decoder = PerceiverDecoder(query_channels=query_channels, final_project=final_project,
+                                         final_project_out_channels=final_project_out_channels,
+                                         num_latent_channels=num_latent_channels, **perceiver_decoder_kwargs)
+
+    def decoder_query(self, inputs, modality_sizes, inputs_without_pos=None, subsampled_points=None):
+        per_mod = restructure(modality_sizes, inputs)
+        subsampled_points = subsampled_points or {}
+        any_input = next(iter(per_mod.values()))
+        queries = {}
+        for m, make_query in self._output_queries.items():
+            wo = inputs_without_pos.get(m) if inputs_without_pos is not None else None
+            src = per_mod.get(m)
+            if src is None:      # a query without a matching input still needs batch size / device
+                src = torch.zeros((any_input.shape[0], 0), device=any_input.device)
+            q = make_query(src, inputs_without_pos=wo, subsampled_points=subsampled_points.get(m))
+            q = q.reshape(q.shape[0], -1, q.shape[-1])
+            pad = torch.broadcast_to(self.padding_embeddings[m](q.shape[0]),
+                                     [q.shape[0], q.shape[1], self.query_channels - q.shape[2]])
+            queries[m] = torch.cat([q, pad], dim=2) if pad.shape[2] > 0 else q
+        sizes = {m: q.shape[1] for m, q in queries.items()}
+        if len(queries) == 1:
+            return next(iter(queries.values())), sizes        # keeps a broadcast table a stride-0 view
+        return torch.cat([queries[m] for m in sorted(queries.keys())], dim=1), sizes
+
+    def forward(self, inputs, *, subsampled_output_points=None, pos=None, input_mask=None, query_mask=None):
+        if type(inputs) is torch.Tensor:
+            inputs = {"__default": inputs}
+        x, sizes, without_pos = self._multi_preprocessor(inputs, pos=pos)
+        latents0 = self._encoder.latents(x)
+        query, query_sizes = self.decoder_query(x, sizes, without_pos, subsampled_points=subsampled_output_points)
+        latents = self._encoder(x, latents0, input_mask=input_mask)
+        outputs = self._decoder(query, latents, query_mask=query_mask)
+        if self._output_postprocessors:
+            per_mod = restructure(query_sizes, outputs)
+            outputs = {m: post(per_mod[m], pos=None, modality_sizes=None)
+                       for m, post in self._output_postprocessors.items()}
+        if type(outputs) is not torch.Tensor and list(outputs.keys()) == ["__default"]:
+            outputs = outputs["__default"]
+        return outputs

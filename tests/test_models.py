@@ -1,0 +1,82 @@
+"""Whole task models ("next" rows of SURVEY.md 8f): state_dict layout on CPU, outputs against reference goldens on GPU."""
+import numpy as np
+import pytest
+import torch
+
+import perceiver_oracle as O
+from cases import MODEL_CASES, gen_state_dict, model_inputs
+from _golden import load
+
+TOL = 1e-3
+
+
+def build(name):
+    from perceiverio_pytorch_amd import models as M
+    c = MODEL_CASES[name]
+    kw = dict(c["kw"])
+    if c["cls"] == "ClassificationPerceiver":
+        return M.ClassificationPerceiver(prep_type=M.PrepType[kw.pop("prep")])
+    return getattr(M, c["cls"])(**kw)
+
+
+def spec_of(g):
+    return [(str(n), tuple(int(d) for d in str(s).split(",") if d != "")) for n, s in
+            zip(g["spec_names"], g["spec_shapes"])]
+
+
+@pytest.mark.parametrize("name", sorted(MODEL_CASES))
+def test_state_dict_layout_equals_reference(name):
+    """Every key and shape of the reference model's state_dict (frozen in the golden) exists here, and nothing else:
+    a reference checkpoint loads with strict=True."""
+    g = load(name)
+    ref = dict(spec_of(g))
+    mine = {k: tuple(v.shape) for k, v in build(name).state_dict().items()}
+    assert mine == ref
+
+
+def _load_generated(model, g, dev):
+    params = gen_state_dict(spec_of(g), 31)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
+    return model.to(dev).eval()
+
+
+def _close(y, ref, what, tol=TOL, absmax=None):
+    y = y.detach().float().cpu().numpy().astype(np.float64)
+    d = y - ref.astype(np.float64)
+    am = float(absmax) if absmax is not None else np.abs(ref).max()
+    rl2 = np.sqrt((d * d).sum()) / np.sqrt((ref.astype(np.float64) ** 2).sum())
+    rmax = np.abs(d).max() / am
+    print(f"{what}: relL2={rl2:.3e} max/absmax={rmax:.3e}")
+    assert rl2 <= tol and rmax <= tol, f"{what}: relL2={rl2:.3e} max/absmax={rmax:.3e}"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("policy", ["fp16x3", "fp16x2w"])
+@pytest.mark.parametrize("name", sorted(MODEL_CASES))
+def test_model_outputs_match_reference(name, policy):
+    import perceiverio_pytorch_amd as P
+    dev = torch.device("cuda:0")
+    P.set_precision_policy(policy)
+    g = load(name)
+    c = MODEL_CASES[name]
+    model = _load_generated(build(name), g, dev)
+    ins = [torch.from_numpy(a).to(dev) for a in model_inputs(name)]
+    tol = TOL if policy != "fp16x3" else 1e-4
+    with torch.inference_mode():
+        if c["cls"] == "FlowPerceiver":
+            _close(model(ins[0][..., :48, :64], ins[1][..., :48, :64]), g["out_train"], name + " train", tol)
+            _close(model(ins[0], ins[1], test_mode=True, min_overlap=10), g["out_test"], name + " tiled", tol)
+        elif c["cls"] == "MultiModalPerceiver":
+            out = model(ins[0], ins[1], n_chunks=2)
+            _close(out["image"], g["out_image"], name + " image", tol)
+            _close(out["audio"], g["out_audio"], name + " audio", tol)
+            _close(out["label"], g["out_label"], name + " label", tol)
+            model.encode_once = False            # the reference's recompute-per-chunk loop gives the same result
+            out2 = model(ins[0], ins[1], n_chunks=2)
+            assert torch.equal(out2["image"], out["image"]) and torch.equal(out2["label"], out["label"])
+        elif c["cls"] == "LanguagePerceiver":
+            out = model(ins[0], ins[1])
+            _close(out[:, :96], g["out"], name + " head", tol, absmax=g["out_absmax"])
+            _close(out[:, 640:704], g["out_tail"], name + " tail", tol, absmax=g["out_absmax"])
+        else:
+            _close(model(ins[0]), g["out"], name, tol)
