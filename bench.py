@@ -1,20 +1,24 @@
 #!/usr/bin/env python3
-"""Headline benchmark: PerceiverIO forward hot path, ImageNet-224 (conv preprocessing) configuration.
+"""Headline benchmark: PerceiverIO forward, ImageNet-224 classifier (BASELINE.json configs[1]).
 
-One "step" = one pass of the hot path over one batch of synthetic input that is already resident in HBM:
-    inputs [B,3136,322] fp32  ->  PerceiverEncoder (cross-attend into 512x1024 latents, 8 blocks x 6
-    weight-shared self-attends)  ->  PerceiverDecoder (1000 learned queries x 1024, query residual, final
-    Linear 1024->1000)  ->  logits of query row 0 (ClassificationPostprocessor, postprocessors.py:187)
-with B = 32 per GPU (BASELINE.json configs[1]).  Every decoder row is computed (as the reference does).
+One "step" = one full forward of ClassificationPerceiver (PrepType.FOURIER_POS_CONVNET) on a batch of synthetic
+images that is already resident in HBM:
+    images [B,3,224,224] fp32 -> conv preprocessing + Fourier features (torch/MIOpen plumbing, [B,3136,322])
+    -> PerceiverEncoder (cross-attend into 512x1024 latents, 8 blocks x 6 weight-shared self-attends)
+    -> PerceiverDecoder (1000 learned queries x 1024, query residual, final Linear 1024->1000)
+    -> logits of query row 0 [B,1000]
+with B = 32 per GPU.  Every decoder row is computed (as the reference does); the hot path (encoder + decoder,
+99.9 % of the FLOPs) runs in libpio_hip.so.  `--hot-path-only` times just that on a resident [B,3136,322] array.
 
     python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (one rank per GPU, RCCL)
 
-Rank 0 prints ONE JSON line (see README/DESIGN.md for the fields).  Extra objects:
-  roofline     -- the dominant kernel (the linear-layer MFMA GEMM): ALGORITHMIC flops / device time measured
-                  with HIP events around every launch of that kernel in an instrumented repeat of the step
-  cpu_baseline -- the numpy oracle ("port") timed on this host's cores on a bounded sample (rank 0, N=1 only)
-  parity       -- in-run check of the same model at B=2 against the committed reference golden
+Rank 0 prints ONE JSON line.  Extra objects:
+  roofline     -- the dominant kernel (gemm_nt_256, the weight GEMMs of the latent stack): ALGORITHMIC flops / device
+                  time measured with HIP events around every launch of that kernel in an instrumented repeat of the
+                  step; `traffic` = HBM bytes per launch from the committed PMC profile (profiles/traffic.json)
+  cpu_baseline -- the numpy oracle ("port") of the hot path timed on this host's cores on a bounded sample
+  parity       -- in-run check of the same model at B=2 against the committed REFERENCE golden (gate 1e-3)
 """
 from __future__ import annotations
 
@@ -26,7 +30,7 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-for p in (ROOT, os.path.join(ROOT, "oracle")):
+for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
@@ -34,58 +38,55 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 CFG = dict(M=3136, C=322, N=512, D=1024, L=6, blocks=8, xh=1, sh=8, Q=1000, Dq=1024, out=1000)
-# algorithmic GFLOP per sample (2*m*n*k per product, reference formulation)
+# algorithmic GFLOP per sample of the hot path (2*m*n*k per product, reference formulation);
+# the conv preprocessing adds 0.24 GFLOP (0.06 %) and is not counted.
 GFLOP_PER_SAMPLE = 381.65
 MFMA_PEAK_TFLOPS = 2500.0    # dense fp16/bf16, MI355X_MICROARCH.md chip table
-SEED = 21                    # same generator seed as the committed golden "encdec_imagenet_b2"
+GOLDEN = "model_classify_conv"
+SEED = 31                    # parameter seed of the committed whole-model goldens
 
 
-def build(dev, policy):
-    import perceiver_oracle as O
+def build_model(dev, policy):
+    """ClassificationPerceiver with the deterministic parameters of the committed golden (names/shapes of the
+    reference state_dict are frozen in the fixture; values come from the seeded generator)."""
     import perceiverio_pytorch_amd as P
-    from perceiverio_pytorch_amd.perceiver import PerceiverDecoder, PerceiverEncoder
+    from cases import gen_state_dict
+    from perceiverio_pytorch_amd.models import ClassificationPerceiver
     P.set_precision_policy(policy)
-    p_enc = O.gen_encoder(CFG["C"], CFG["N"], CFG["D"], CFG["L"], SEED)
-    p_dec = O.gen_decoder(CFG["Dq"], CFG["D"], CFG["out"], SEED + 1)
-    qtab = O.gen_tensor("query_table", (CFG["Q"], CFG["Dq"]), SEED, "table")
-    enc = PerceiverEncoder(CFG["C"], CFG["L"], CFG["blocks"], CFG["N"], CFG["D"], num_self_attend_heads=CFG["sh"])
-    dec = PerceiverDecoder(CFG["Dq"], CFG["out"], CFG["D"], use_query_residual=True)
-    enc.load_state_dict({k: torch.from_numpy(v) for k, v in p_enc.items()}, strict=True)
-    dec.load_state_dict({k: torch.from_numpy(v) for k, v in p_dec.items()}, strict=True)
-    return enc.to(dev).eval(), dec.to(dev).eval(), torch.from_numpy(qtab).to(dev), (p_enc, p_dec, qtab)
+    g = np.load(os.path.join(ROOT, "tests", "golden", GOLDEN + ".npz"))
+    spec = [(str(n), tuple(int(d) for d in str(s).split(",") if d != "")) for n, s in
+            zip(g["spec_names"], g["spec_shapes"])]
+    params = gen_state_dict(spec, SEED)
+    model = ClassificationPerceiver()
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
+    return model.to(dev).eval(), params, g
 
 
-def forward(enc, dec, qtab, x):
-    z = enc(x, enc.latents(x))
-    y = dec(torch.broadcast_to(qtab[None], (x.shape[0],) + qtab.shape), z)
-    return y
-
-
-def parity_check(enc, dec, qtab, dev):
-    """B=2 run on the golden's seeded input vs the reference float32 output frozen in tests/golden."""
-    from cases import _rand
-    g = np.load(os.path.join(ROOT, "tests", "golden", "encdec_imagenet_b2.npz"))
-    x = torch.from_numpy(_rand("encdec_imagenet_b2" + "x", (2, CFG["M"], CFG["C"]), SEED)).to(dev)
+def parity_check(model, g, dev):
+    """B=2 run on the golden's seeded images vs the reference's float32 logits frozen in tests/golden."""
+    from cases import model_inputs
+    x = torch.from_numpy(model_inputs(GOLDEN)[0]).to(dev)
     with torch.inference_mode():
-        y = forward(enc, dec, qtab, x)
-    sub = y[:, torch.from_numpy(g["out_rows"]).to(dev), :].cpu().numpy().astype(np.float64)
-    d = sub - g["out"].astype(np.float64)
-    rl2 = float(np.sqrt((d * d).sum()) / np.sqrt((g["out"].astype(np.float64) ** 2).sum()))
-    rmax = float(np.abs(d).max() / float(g["out_absmax"]))
-    return rl2, rmax
+        y = model(x).cpu().numpy().astype(np.float64)
+    ref = g["out"].astype(np.float64)
+    d = y - ref
+    return float(np.sqrt((d * d).sum()) / np.sqrt((ref * ref).sum())), float(np.abs(d).max() / np.abs(ref).max())
 
 
 def cpu_baseline(params, sample_b):
+    """numpy oracle of the hot path (encoder + decoder) on a [B,3136,322] sample, same parameters."""
     import perceiver_oracle as O
     from cases import _rand
-    p_enc, p_dec, qtab = params
+    enc = {k[len("perceiver._encoder."):]: v for k, v in params.items() if k.startswith("perceiver._encoder.")}
+    dec = {k[len("perceiver._decoder."):]: v for k, v in params.items() if k.startswith("perceiver._decoder.")}
+    qtab = params["perceiver._output_queries.__default._position_encoding.pos_embs"]
     kw = dict(num_blocks=CFG["blocks"], num_self_attends_per_block=CFG["L"], num_cross_attend_heads=1,
               num_self_attend_heads=CFG["sh"], encoder_query_residual=True, decoder_heads=1,
               decoder_query_residual=True, final_project=True)
     x = _rand("cpu_baseline_x", (sample_b, CFG["M"], CFG["C"]), SEED)
-    O.encode_decode(p_enc, p_dec, x[:1], qtab, **kw)            # warm-up (BLAS threads, page-in)
+    O.encode_decode(enc, dec, x[:1], qtab, **kw)            # warm-up (BLAS threads, page-in)
     t0 = time.perf_counter()
-    O.encode_decode(p_enc, p_dec, x, qtab, **kw)
+    O.encode_decode(enc, dec, x, qtab, **kw)
     dt = time.perf_counter() - t0
     return sample_b / dt, dt
 
@@ -99,14 +100,14 @@ def main():
     ap.add_argument("--policy", default=os.environ.get("PIO_BENCH_POLICY", "fp16"))
     ap.add_argument("--cpu-sample", type=int, default=4, help="batch of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--hot-path-only", action="store_true", help="time encoder+decoder on a resident [B,3136,322] array")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    if world == 1 and args.gpus > 1:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
@@ -122,15 +123,26 @@ def main():
     lib = P.lib()
     assert lib.pio_arch_ok() == 1, "libpio_hip.so is gfx950-only"
 
-    enc, dec, qtab, params = build(dev, args.policy)
+    model, params, golden = build_model(dev, args.policy)
     B = args.batch
     gen = torch.Generator(device="cpu").manual_seed(1000 + rank)
-    x = torch.randn(B, CFG["M"], CFG["C"], generator=gen).to(dev)          # resident in HBM before timing
+    if args.hot_path_only:
+        x = torch.randn(B, CFG["M"], CFG["C"], generator=gen).to(dev)
+        pio = model.perceiver
+        qtab = pio._output_queries["__default"]._position_encoding.pos_embs
+
+        def forward(inp):
+            z = pio._encoder(inp, pio._encoder.latents(inp))
+            return pio._decoder(torch.broadcast_to(qtab[None], (inp.shape[0],) + qtab.shape), z)[:, 0, :]
+    else:
+        x = torch.randn(B, 3, 224, 224, generator=gen).to(dev)     # resident in HBM before the timed region
+        forward = model
 
     parity = None
     if not args.no_parity and rank == 0:
-        rl2, rmax = parity_check(enc, dec, qtab, dev)
-        parity = {"relL2": rl2, "max_abs_over_absmax": rmax, "tol": 1e-3, "case": "encdec_imagenet_b2 (B=2)",
+        rl2, rmax = parity_check(model, golden, dev)
+        parity = {"relL2": rl2, "max_abs_over_absmax": rmax, "tol": 1e-3,
+                  "case": "ClassificationPerceiver B=2 vs reference fp32 logits (tests/golden/model_classify_conv.npz)",
                   "ok": bool(rl2 <= 1e-3 and rmax <= 1e-3)}
         if not parity["ok"]:
             raise SystemExit(f"parity gate failed for policy {args.policy}: {parity}")
@@ -138,8 +150,7 @@ def main():
     gathered = [torch.empty(B, CFG["out"], device=dev) for _ in range(world)] if world > 1 else None
 
     def step():
-        y = forward(enc, dec, qtab, x)
-        logits = y[:, 0, :]                                   # ClassificationPostprocessor keeps query row 0
+        logits = forward(x)                                   # [B,1000]: query row 0 (ClassificationPostprocessor)
         if world > 1:
             dist.all_gather(gathered, logits.contiguous())    # the path's only collective (RCCL over xGMI);
             # same call as perceiverio_pytorch_amd.dist.all_gather_rows, with the receive list pre-allocated
@@ -203,14 +214,17 @@ def main():
                 "avg_launch_us": g["avg_us"], "launches_per_step": g["launches_per_step"],
                 "algo_flops_per_launch": fl[0] / ln[0], "algo_bytes_per_launch": by[0] / ln[0]}
 
+    workload = ("imagenet224 ClassificationPerceiver (conv+Fourier prep -> encoder 3136x322->512x1024, 8x6 SA -> decoder "
+                "1000 queries -> final Linear), all rows computed")
+    if args.hot_path_only:
+        workload = "hot path only (encoder + decoder + final Linear) on a resident [B,3136,322] array"
     out = {
-        "metric": "samples/sec PerceiverIO fwd (ImageNet-224 conv cfg, 512x1024 latents, 8x6 self-attends)",
+        "metric": "samples/sec PerceiverIO fwd (ImageNet-224, 512x1024 latents, 8 blocks x 6 self-attends)",
         "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f16" if args.policy.startswith("fp16") else "bf16", "data": "synthetic",
-        "config": {"workload": "imagenet224_conv hot path: encoder(3136x322 -> 512x1024, 8x6 SA) + decoder(1000 "
-                               "queries) + final Linear, all rows computed", "batch_per_gpu": B,
-                   "global_batch": B * world, "precision_policy": args.policy,
+        "config": {"workload": workload, "batch_per_gpu": B, "global_batch": B * world,
+                   "precision_policy": args.policy,
                    "parallelism": f"dp{world} (batch sharded, all-gather of logits)"},
         "per_gpu": value / world,
         "model_algo_tflops": value * GFLOP_PER_SAMPLE / 1e3,
@@ -220,8 +234,9 @@ def main():
     if rank == 0 and world == 1 and args.cpu_sample > 0:
         v, dt = cpu_baseline(params, args.cpu_sample)
         out["cpu_baseline"] = {"value": v, "unit": "samples/s", "cores": os.cpu_count(), "kind": "port",
-                               "sample": f"numpy fp32 oracle, same model, B={args.cpu_sample}, one forward "
-                                         f"({dt:.1f} s) after a B=1 warm-up"}
+                               "sample": f"numpy fp32 oracle of the hot path (encoder+decoder, 99.9% of the model's "
+                                         f"FLOPs), same parameters, B={args.cpu_sample}, one forward ({dt:.1f} s) after "
+                                         f"a B=1 warm-up"}
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

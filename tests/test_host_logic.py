@@ -95,3 +95,40 @@ def test_mask_helper_matches_oracle():
     g = load("mask")
     m = make_cross_attention_mask(torch.from_numpy(g["query_mask"]), torch.from_numpy(g["kv_mask"]))
     assert m.dtype == torch.bool and np.array_equal(m.numpy(), g["mask"])
+
+
+def test_reference_import_paths_resolve():
+    """The reference's example scripts import these names; the shims must keep them alive."""
+    from perceiver_io.classification_perceiver import ClassificationPerceiver, PrepType            # noqa: F401
+    from perceiver_io.multimodal_perceiver import MultiModalPerceiver                             # noqa: F401
+    from perceiver_io.language_perceiver import LanguagePerceiver                                 # noqa: F401
+    from perceiver_io.flow_perceiver import FlowPerceiver                                         # noqa: F401
+    from perceiver_io.perceiver import PerceiverIO, PerceiverEncoder, PerceiverDecoder            # noqa: F401
+    from perceiver_io.transformer_primitives import Attention, CrossAttention, MLP, SelfAttention  # noqa: F401
+    from perceiver_io.io_processors.preprocessors import ImagePreprocessor                        # noqa: F401
+    from perceiver_io.io_processors.postprocessors import ClassificationPostprocessor             # noqa: F401
+    from perceiver_io.output_queries import TrainableQuery, FourierQuery, FlowQuery               # noqa: F401
+    from utils.bytes_tokenizer import BytesTokenizer
+    from utils.flow_utils import flow_to_image
+    from utils.utils import load_image, show_animation                                            # noqa: F401
+    from utils.imagenet_labels import IMAGENET_LABELS
+    from utils.kinetics_700_classes import KINETICS_CLASSES
+    t = BytesTokenizer()
+    ids = t.to_int("Perceiver IO")
+    assert t.to_string(ids) == "Perceiver IO" and int(ids.min()) >= 6 and t.vocab_size == 262 and t.mask_token == 3
+    assert flow_to_image(np.zeros((3, 4, 2))).shape == (3, 4, 3)
+    assert len(IMAGENET_LABELS) == 1000 and len(KINETICS_CLASSES) == 700
+
+
+def test_perceiver_io_constructor_surface():
+    """The five north_star constructor names + the raw (no pre/post-processor) usage of SURVEY appendix C."""
+    from perceiver_io.output_queries import TrainableQuery
+    from perceiver_io.perceiver import PerceiverIO
+    m = PerceiverIO(num_blocks=2, num_self_attends_per_block=2, num_latents=8, num_latent_channels=16,
+                    input_channels=24, output_queries=TrainableQuery(output_index_dims=5, num_channels=12),
+                    perceiver_encoder_kwargs=dict(num_self_attend_heads=4))
+    keys = set(m.state_dict())
+    assert "padding_embeddings.__default.pos_embs" in keys and "_encoder.latent_pos_enc.pos_embs" in keys
+    assert "_output_queries.__default._position_encoding.pos_embs" in keys
+    assert m.state_dict()["padding_embeddings.__default.pos_embs"].shape == (1, 0)
+    assert len(keys) == 73
