@@ -160,7 +160,7 @@ class _PosMixin:
                 self._extra_pos_mlps.append(lin)
 
     def _attach_pos(self, feats: torch.Tensor, pos):
-        enc = self._positional_encoding(batch_size=feats.shape[0], pos=pos).to(feats.device)
+        enc = self._positional_encoding(batch_size=feats.shape[0], pos=pos, device=feats.device).to(feats.device)
         for i in range(self._n_extra_pos_mlp):
             enc = enc + self._extra_pos_mlps[i](enc)
             if i < self._n_extra_pos_mlp - 1:

@@ -54,10 +54,10 @@ class BasicQuery(nn.Module):
                 coords = unravel_index(subsampled_points.to(inputs.device), self._output_index_dim)
                 pos = -1 + 2 * coords / dims[None, :]
                 pos = torch.broadcast_to(pos[None], (batch,) + tuple(pos.shape))
-                enc = self._position_encoding(batch_size=batch, pos=pos)
+                enc = self._position_encoding(batch_size=batch, pos=pos, device=inputs.device)
                 enc = enc.reshape(batch, -1, enc.shape[-1])
             else:
-                enc = self._position_encoding(batch_size=batch)
+                enc = self._position_encoding(batch_size=batch, device=inputs.device)
             enc = enc.to(inputs.device)
         if self._concat_preprocessed_input:
             if inputs_without_pos is None:

@@ -58,8 +58,8 @@ class TrainablePositionEncoding(nn.Module):
             nn.init.trunc_normal_(self.pos_embs, std=init_scale, a=-2.0, b=2.0)
         self._output_channels = num_channels
 
-    def forward(self, batch_size, pos=None):
-        del pos
+    def forward(self, batch_size, pos=None, device=None):
+        del pos, device
         if batch_size is not None:
             pos_embs = torch.broadcast_to(self.pos_embs[None, :, :], (batch_size,) + self.pos_embs.shape)
         return pos_embs  # batch_size=None raises UnboundLocalError, like the reference (:119-121)
@@ -81,16 +81,27 @@ class FourierPositionEncoding(nn.Module):
         self._max_resolution = max_resolution or index_dims
         d = len(self._max_resolution)
         self._output_channels = d * num_bands * (1 if sine_only else 2) + (d if concat_pos else 0)
+        self._grid_tables = {}   # device -> [prod(index_dims), C] table of the regular grid (input-independent)
 
-    def forward(self, batch_size, pos=None):
+    def forward(self, batch_size, pos=None, device=None):
+        """``device`` (optional) asks for the result on that device; the regular-grid table is then built once
+        (on the host, with the reference's exact float32 arithmetic) and cached there instead of being recomputed
+        and copied on every forward as the reference does."""
         if pos is None:
-            grid = build_linear_positions(self._index_dims)
-            points = grid.reshape(-1, grid.shape[-1])
+            key = str(device)
+            enc = self._grid_tables.get(key)
+            if enc is None:
+                grid = build_linear_positions(self._index_dims)
+                enc = generate_fourier_features(grid.reshape(-1, grid.shape[-1]), num_bands=self._num_bands,
+                                                max_resolution=self._max_resolution, concat_pos=self._concat_pos,
+                                                sine_only=self._sine_only)
+                if device is not None:
+                    enc = enc.to(device)
+                self._grid_tables[key] = enc
         else:
             assert pos.shape[-1] == len(self._index_dims)
-            points = pos[0]
-        enc = generate_fourier_features(points, num_bands=self._num_bands, max_resolution=self._max_resolution,
-                                        concat_pos=self._concat_pos, sine_only=self._sine_only)
+            enc = generate_fourier_features(pos[0], num_bands=self._num_bands, max_resolution=self._max_resolution,
+                                            concat_pos=self._concat_pos, sine_only=self._sine_only)
         if batch_size is not None:
             enc = torch.broadcast_to(enc[None], (batch_size,) + enc.shape)
         return enc
@@ -111,8 +122,8 @@ class PositionEncodingProjector(nn.Module):
         lecun_normal_(self._projector.weight)
         nn.init.constant_(self._projector.bias, 0)
 
-    def forward(self, batch_size, pos=None):
-        return self._projector(self._base_position_encoding(batch_size, pos))
+    def forward(self, batch_size, pos=None, device=None):
+        return self._projector(self._base_position_encoding(batch_size, pos, device=device))
 
     def n_output_channels(self):
         return self._output_channels
