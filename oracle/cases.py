@@ -104,6 +104,8 @@ MODEL_CASES = {
     "model_language": dict(cls="LanguagePerceiver", kw=dict(), batch=2),
     "model_flow_small": dict(cls="FlowPerceiver", kw=dict(img_size=(48, 64), num_latents=128, num_latent_channels=128,
                                                           num_self_attends_per_block=2), batch=1),
+    # full-size optical-flow configuration: M = Q = 368*496 = 182 528 tokens, 2048 x 512 latents, 24 self-attends
+    "model_flow_full": dict(cls="FlowPerceiver", kw=dict(), batch=1),
     "model_multimodal_small": dict(cls="MultiModalPerceiver",
                                    kw=dict(img_size=(16, 16), num_frames=2, num_classes=10,
                                            audio_samples_per_frame=32, audio_samples_per_patch=16,
@@ -127,7 +129,8 @@ def model_inputs(name, seed=31):
         tok[~mask] = 0
         return [tok, mask]
     if c["cls"] == "FlowPerceiver":
-        return [_rand(name + "i1", (B, 3, 60, 80), seed), _rand(name + "i2", (B, 3, 60, 80), seed)]
+        hw = (368, 496) if name == "model_flow_full" else (60, 80)
+        return [_rand(name + "i1", (B, 3) + hw, seed), _rand(name + "i2", (B, 3) + hw, seed)]
     if c["cls"] == "MultiModalPerceiver":
         kw = c["kw"]
         return [np.abs(_rand(name + "v", (B, kw["num_frames"], 3) + tuple(kw["img_size"]), seed)),

@@ -329,7 +329,12 @@ def case_models(only=None):
         save = dict(spec_names=np.array([k for k, _ in spec]),
                     spec_shapes=np.array([",".join(str(d) for d in s) for _, s in spec]))
         with torch.inference_mode():
-            if c["cls"] == "FlowPerceiver":
+            if name == "model_flow_full":
+                out = model(tin[0], tin[1]).numpy()                      # [1, 2, 368, 496]
+                save.update(out_sub=out[:, :, ::8, ::8], out_absmax=np.array(np.abs(out).max()),
+                            out_l2=np.array(np.sqrt((out.astype(np.float64) ** 2).sum())))
+                print(f"{name:42s} flow {out.shape} absmax {np.abs(out).max():.3f}")
+            elif c["cls"] == "FlowPerceiver":
                 out_train = model(tin[0][..., :48, :64], tin[1][..., :48, :64]).numpy()
                 out_test = model(tin[0], tin[1], test_mode=True, min_overlap=10).numpy()
                 save.update(out_train=out_train, out_test=out_test)
