@@ -59,6 +59,7 @@ def build_model(dev, policy):
     params = gen_state_dict(spec, SEED)
     model = ClassificationPerceiver()
     model.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
+    model.precision_policy = policy         # the benchmarked policy (the class default is fp16x2w)
     return model.to(dev).eval(), params, g
 
 

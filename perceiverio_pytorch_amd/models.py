@@ -17,7 +17,15 @@ from .io_processors import (AudioPostprocessor, AudioPreprocessor, Classificatio
                             OneHotPreprocessor, ProjectionPostprocessor, patches_for_flow)
 from .output_queries import FlowQuery, FourierQuery, TrainableQuery
 from .perceiver import PerceiverIO
+from .runtime import precision
 from .position_encoding import PosEncodingType
+
+
+# Precision policy each task model runs under unless `model.precision_policy` is changed (None = the global policy of
+# perceiverio_pytorch_amd.set_precision_policy).  The defaults are the fastest policies that meet the 1e-3 parity bar
+# against the reference on that architecture (tests/test_models.py).
+DEFAULT_POLICY = {"ClassificationPerceiver": "fp16x2w", "LanguagePerceiver": "fp16x2w", "FlowPerceiver": "fp16x3",
+                  "MultiModalPerceiver": "fp16x3"}
 
 
 class PrepType(Enum):
@@ -32,8 +40,10 @@ class ClassificationPerceiver(nn.Module):
 
     def __init__(self, num_classes: int = 1000, img_size: Sequence[int] = (224, 224), img_channels: int = 3,
                  prep_type: PrepType = PrepType.FOURIER_POS_CONVNET, num_self_attends_per_block: int = 6,
-                 num_blocks: int = 8, num_latents: int = 512, num_latent_channels: int = 1024):
+                 num_blocks: int = 8, num_latents: int = 512, num_latent_channels: int = 1024,
+                 precision_policy: str = DEFAULT_POLICY["ClassificationPerceiver"]):
         super().__init__()
+        self.precision_policy = precision_policy
         fourier = dict(concat_pos=True, num_bands=64, sine_only=False)
         if prep_type == PrepType.FOURIER_POS_CONVNET:
             prep = ImagePreprocessor(img_size=img_size, input_channels=img_channels, prep_type="conv",
@@ -63,7 +73,8 @@ class ClassificationPerceiver(nn.Module):
 
     def forward(self, img: torch.Tensor):
         """img: (batch, channels, H, W) -> logits (batch, num_classes)."""
-        return self.perceiver(img)
+        with precision(self.precision_policy):
+            return self.perceiver(img)
 
 
 class LanguagePerceiver(nn.Module):
@@ -71,8 +82,9 @@ class LanguagePerceiver(nn.Module):
 
     def __init__(self, vocab_size: int = 262, max_seq_len: int = 2048, embed_dim: int = 768,
                  num_self_attends_per_block: int = 26, num_blocks: int = 1, num_latents: int = 256,
-                 num_latent_channels: int = 1280):
+                 num_latent_channels: int = 1280, precision_policy: str = DEFAULT_POLICY["LanguagePerceiver"]):
         super().__init__()
+        self.precision_policy = precision_policy
         prep = EmbeddingPreprocessor(vocab_size=vocab_size, max_seq_len=max_seq_len, embedding_dims=embed_dim)
         self.perceiver = PerceiverIO(
             final_project=False, num_self_attends_per_block=num_self_attends_per_block, num_blocks=num_blocks,
@@ -85,7 +97,8 @@ class LanguagePerceiver(nn.Module):
             output_queries=TrainableQuery(output_index_dims=max_seq_len, num_channels=embed_dim))
 
     def forward(self, inputs: torch.Tensor, input_masks: torch.Tensor):
-        return self.perceiver(inputs, input_mask=input_masks, query_mask=input_masks)
+        with precision(self.precision_policy):
+            return self.perceiver(inputs, input_mask=input_masks, query_mask=input_masks)
 
 
 class FlowPerceiver(nn.Module):
@@ -93,8 +106,10 @@ class FlowPerceiver(nn.Module):
 
     def __init__(self, img_size: Sequence[int] = (368, 496), flow_scale_factor: int = 20 / 100,
                  num_latents: int = 2048, num_latent_channels=512, num_self_attends_per_block: int = 24,
-                 num_blocks: int = 1, mixed_precision: bool = False):
+                 num_blocks: int = 1, mixed_precision: bool = False,
+                 precision_policy: str = DEFAULT_POLICY["FlowPerceiver"]):
         super().__init__()
+        self.precision_policy = precision_policy
         self._flow_scale_factor = flow_scale_factor
         self.mixed_precision = mixed_precision    # kept for signature parity: precision is set by the policy here
         prep = ImagePreprocessor(img_size=img_size, input_channels=3 * 3 ** 2, prep_type="patches",
@@ -129,7 +144,8 @@ class FlowPerceiver(nn.Module):
         return itertools.product(ys, xs)
 
     def _predict_patch(self, patch):
-        return self.perceiver(patches_for_flow(patch).movedim(-1, -3))
+        with precision(self.precision_policy):
+            return self.perceiver(patches_for_flow(patch).movedim(-1, -3))
 
     def forward(self, image1: torch.Tensor, image2: torch.Tensor, test_mode: bool = False, min_overlap: int = 20):
         h, w = image1.shape[2], image1.shape[3]
@@ -166,8 +182,10 @@ class MultiModalPerceiver(nn.Module):
     def __init__(self, img_size: Sequence[int] = (224, 224), img_channels: int = 3, num_frames: int = 16,
                  num_classes: int = 700, audio_samples_per_frame: int = 48000 // 25,
                  audio_samples_per_patch: int = 16, num_self_attends_per_block: int = 8, num_blocks: int = 1,
-                 num_latents: int = 28 * 28 * 1, num_latent_channels: int = 512, encode_once: bool = True):
+                 num_latents: int = 28 * 28 * 1, num_latent_channels: int = 512, encode_once: bool = True,
+                 precision_policy: str = DEFAULT_POLICY["MultiModalPerceiver"]):
         super().__init__()
+        self.precision_policy = precision_policy
         self.H, self.W = img_size
         self.num_classes = num_classes
         self.audio_samples_per_frame = audio_samples_per_frame
@@ -210,6 +228,10 @@ class MultiModalPerceiver(nn.Module):
             input_mask_probs={"image": 0.0, "audio": 0.0, "label": 1.0})
 
     def forward(self, images: torch.Tensor, audio: torch.Tensor, n_chunks: int = 128):
+        with precision(self.precision_policy):
+            return self._forward(images, audio, n_chunks)
+
+    def _forward(self, images, audio, n_chunks):
         b, t, c, h, w = images.shape
         img_chunk = t * h * w // n_chunks
         aud_chunk = audio.shape[1] // self.audio_samples_per_patch // n_chunks

@@ -40,6 +40,28 @@ def get_precision_policy() -> str:
     return _policy
 
 
+class precision:
+    """Context manager: run a block under another precision policy (None = leave the current one)."""
+
+    def __init__(self, name: Optional[str]):
+        if name is not None and name not in _POLICIES:
+            raise ValueError(f"unknown precision policy {name!r}; choose from {sorted(_POLICIES)}")
+        self._name = name
+        self._saved = None
+
+    def __enter__(self):
+        global _policy
+        self._saved = _policy
+        if self._name is not None:
+            _policy = self._name
+        return self
+
+    def __exit__(self, *exc):
+        global _policy
+        _policy = self._saved
+        return False
+
+
 def policy_dtype(name: Optional[str] = None) -> Tuple[int, bool, bool]:
     """(operand dtype, weights split, activations split)"""
     return _POLICIES[name or _policy]

@@ -24,6 +24,13 @@ def spec_of(g):
             zip(g["spec_names"], g["spec_shapes"])]
 
 
+def test_default_policies_are_the_validated_ones():
+    from perceiverio_pytorch_amd import models as M
+    assert M.ClassificationPerceiver().precision_policy == "fp16x2w"
+    assert M.DEFAULT_POLICY == {"ClassificationPerceiver": "fp16x2w", "LanguagePerceiver": "fp16x2w",
+                                "FlowPerceiver": "fp16x3", "MultiModalPerceiver": "fp16x3"}
+
+
 @pytest.mark.parametrize("name", sorted(MODEL_CASES))
 def test_state_dict_layout_equals_reference(name):
     """Every key and shape of the reference model's state_dict (frozen in the golden) exists here, and nothing else:
@@ -56,10 +63,10 @@ def _close(y, ref, what, tol=TOL, absmax=None):
 def test_model_outputs_match_reference(name, policy):
     import perceiverio_pytorch_amd as P
     dev = torch.device("cuda:0")
-    P.set_precision_policy(policy)
     g = load(name)
     c = MODEL_CASES[name]
     model = _load_generated(build(name), g, dev)
+    model.precision_policy = policy            # overrides the per-class default (models.DEFAULT_POLICY)
     ins = [torch.from_numpy(a).to(dev) for a in model_inputs(name)]
     tol = TOL if policy != "fp16x3" else 1e-4
     with torch.inference_mode():

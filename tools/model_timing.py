@@ -6,7 +6,7 @@ import perceiverio_pytorch_amd as P
 from perceiverio_pytorch_amd.models import ClassificationPerceiver
 P.set_precision_policy("fp16")
 dev = torch.device("cuda:0")
-m = ClassificationPerceiver().to(dev).eval()
+m = ClassificationPerceiver(precision_policy="fp16").to(dev).eval()
 x = torch.randn(32, 3, 224, 224, device=dev)
 pio = m.perceiver
 def t(fn, n=10):
