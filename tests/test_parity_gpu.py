@@ -411,3 +411,67 @@ def test_oracle_same_inputs_mid(dev):
     ref = O.encode_decode(c64(p_enc), c64(p_dec), x.astype(np.float64), qtab.astype(np.float64),
                           **encdec_kwargs(cfg, im, qm))
     _assert_close(y, ref, TIGHT, what="tails")
+
+
+# ----------------------------------------------------------------------------------------------------
+# edge cases the reference's semantics define
+# ----------------------------------------------------------------------------------------------------
+def test_encoder_sample_with_every_input_token_masked(dev):
+    """A sample whose key mask is all-false: every latent row is "wiped" -> attention output = final.bias, then the
+    residual / MLP as usual (transformer_primitives.py:168-175; SURVEY appendix A "masked-row consequences")."""
+    _policy("fp16x3")
+    cfg = dict(B=3, M=37, C=24, N=16, D=32, L=1, blocks=1, xh=2, sh=4, enc_resid=True, Q=5, Dq=24, out=None, dh=2,
+               dec_resid=False, masks=True, qk=16, v=32, dqk=16, dv=24)
+    p_enc, p_dec, qtab, x, im, qm = gen_encdec_inputs("allmasked", cfg, 9)
+    im[1, :] = False                     # sample 1: nothing to attend to
+    qm[2, :] = False                     # sample 2: every decoder query masked
+    enc, dec = build_encdec(cfg, p_enc, p_dec, dev)
+    z, y = run_encdec(enc, dec, x, qtab, im, qm, dev)
+    c64 = lambda d: {k: a.astype(np.float64) for k, a in d.items()}  # noqa: E731
+    ref = O.encode_decode(c64(p_enc), c64(p_dec), x.astype(np.float64), qtab.astype(np.float64),
+                          **encdec_kwargs(cfg, im, qm))
+    assert torch.isfinite(y).all()
+    _assert_close(y, ref, TIGHT, what="fully masked samples")
+
+
+def test_strided_and_degenerate_inputs(dev):
+    from perceiverio_pytorch_amd.transformer_primitives import Attention, SelfAttention
+    _policy("fp16x3")
+    rng = np.random.default_rng(3)
+    # (a) a transposed (non-contiguous) view and a float64 input are accepted like any tensor
+    p = O.gen_self_attention("", 32, 4, widening=1)
+    m = SelfAttention(32, widening_factor=1, num_heads=4)
+    m.load_state_dict(_sd(p, "cpu"))
+    m = m.to(dev).eval()
+    base = rng.standard_normal((2, 32, 11))                       # [B, C, T]
+    xv = _t(base, dev).transpose(1, 2)                            # [B, T, C] view with stride(2) != 1
+    ref = O.self_attention({k: a.astype(np.float64) for k, a in p.items()}, base.transpose(0, 2, 1), 4)
+    _assert_close(m(xv), ref, TIGHT, what="strided fp64 input")
+    # (b) one query, one key
+    pa = O.gen_attention("", 16, 16, 16, 16, 16, 5)
+    a = Attention(16, 16, 16, num_heads=2)
+    a.load_state_dict(_sd(pa, "cpu"))
+    a = a.to(dev).eval()
+    xq, xk = rng.standard_normal((1, 1, 16)).astype(np.float32), rng.standard_normal((1, 1, 16)).astype(np.float32)
+    ref = O.attention({k: v.astype(np.float64) for k, v in pa.items()}, xq.astype(np.float64), xk.astype(np.float64),
+                      xk.astype(np.float64), 2)
+    _assert_close(a(_t(xq, dev), _t(xk, dev), _t(xk, dev)), ref, TIGHT, what="1x1 attention")
+    # (c) inputs_k is not inputs_v (generic Attention signature)
+    xv2 = rng.standard_normal((1, 1, 16)).astype(np.float32)
+    ref = O.attention({k: v.astype(np.float64) for k, v in pa.items()}, xq.astype(np.float64), xk.astype(np.float64),
+                      xv2.astype(np.float64), 2)
+    _assert_close(a(_t(xq, dev), _t(xk, dev), _t(xv2, dev)), ref, TIGHT, what="k != v inputs")
+
+
+def test_errors_are_loud(dev):
+    from perceiverio_pytorch_amd import PioError
+    from perceiverio_pytorch_amd.transformer_primitives import SelfAttention
+    m = SelfAttention(32, widening_factor=1, num_heads=4).to(dev).eval()
+    with pytest.raises(PioError, match="PIO_E_SHAPE"):
+        m(torch.zeros(1, 4, 24, device=dev))                      # wrong channel count reaches the C-ABI check
+    with pytest.raises(ValueError):
+        m(torch.zeros(4, 32, device=dev))                         # not [B, T, C]
+    m.train()
+    m2 = SelfAttention(32, widening_factor=1, num_heads=4, dropout_prob=0.1).to(dev)
+    with pytest.raises(NotImplementedError):
+        m2(torch.zeros(1, 4, 32, device=dev))                     # training-mode dropout is not on this path
