@@ -67,10 +67,31 @@ class PerceiverEncoder(nn.Module):
             layers[i] = sa._desc()
         im, im_ptr = R.mask_u8(input_mask, (B, M), dev)
         out = torch.empty((B, N, D), dtype=torch.float32, device=dev)
-        ws = R.workspace(dev, lib.pio_encoder_workspace_bytes(cross, layers, Lyr, B, M, N))
-        L.check(lib.pio_encoder_fwd(cross, layers, Lyr, self._num_blocks, R.tensor3(x), R.tensor3(z0), im_ptr,
-                                    out.data_ptr(), ws.data_ptr(), ws.numel(), R.stream_ptr(dev)),
-                "pio_encoder_fwd")
+        nsplit = R.batch_streams()
+        if nsplit <= 1 or B < 2 * nsplit or B % nsplit:
+            ws = R.workspace(dev, lib.pio_encoder_workspace_bytes(cross, layers, Lyr, B, M, N))
+            L.check(lib.pio_encoder_fwd(cross, layers, Lyr, self._num_blocks, R.tensor3(x), R.tensor3(z0), im_ptr,
+                                        out.data_ptr(), ws.data_ptr(), ws.numel(), R.stream_ptr(dev)),
+                    "pio_encoder_fwd")
+            return out
+        # Samples are independent: run `nsplit` batch slices as independent kernel chains on side streams so that
+        # one chain's fill / drain / HBM-bound kernels overlap the other's MFMA-bound ones (each slice still fills
+        # >= half of the CUs).  Every slice has its own workspace; the current stream waits for all of them.
+        cur = torch.cuda.current_stream(dev)
+        bs = B // nsplit
+        for i, side in enumerate(R.side_streams(dev, nsplit)):
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                xs, zs = x[i * bs:(i + 1) * bs], z0[i * bs:(i + 1) * bs]
+                ws = R.workspace(dev, lib.pio_encoder_workspace_bytes(cross, layers, Lyr, bs, M, N))
+                mp = im_ptr + i * bs * M if im_ptr is not None else None
+                L.check(lib.pio_encoder_fwd(cross, layers, Lyr, self._num_blocks, R.tensor3(xs), R.tensor3(zs), mp,
+                                            out[i * bs:(i + 1) * bs].data_ptr(), ws.data_ptr(), ws.numel(),
+                                            side.cuda_stream), "pio_encoder_fwd")
+            cur.wait_stream(side)
+        for t in (x, z0, out):
+            for side in R.side_streams(dev, nsplit):
+                t.record_stream(side)
         return out
 
 

@@ -139,6 +139,29 @@ def release_workspaces() -> None:
 
 
 # ------------------------------------------------------------------------------------------------
+# optional batch-slice streams for the encoder stack (PIO_STREAMS=k, default 1 = off)
+# ------------------------------------------------------------------------------------------------
+_nstreams = max(1, int(os.environ.get("PIO_STREAMS", "1")))
+_side_streams: Dict[Tuple[int, int], list] = {}
+
+
+def batch_streams() -> int:
+    return _nstreams
+
+
+def set_batch_streams(n: int) -> None:
+    global _nstreams
+    _nstreams = max(1, int(n))
+
+
+def side_streams(device: torch.device, n: int) -> list:
+    key = (device.index if device.index is not None else torch.cuda.current_device(), n)
+    if key not in _side_streams:
+        _side_streams[key] = [torch.cuda.Stream(device=device) for _ in range(n)]
+    return _side_streams[key]
+
+
+# ------------------------------------------------------------------------------------------------
 # packed weights
 # ------------------------------------------------------------------------------------------------
 class PackedLinear:
