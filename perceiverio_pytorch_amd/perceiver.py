@@ -133,7 +133,8 @@ class PerceiverDecoder(nn.Module):
     def _final_desc(self):
         key = R.param_key(self.final_layer.weight, self.final_layer.bias)
         if self._final_cache is None or self._final_cache[0] != key:
-            dtype, two, _split = R.policy_dtype()
+            dtype, wlevel, _split = R.policy_dtype()
+            two = wlevel >= 2
             self._final_cache = (key, R.PackedLinear(self.final_layer.weight, self.final_layer.bias, 1, 1, dtype, two))
         return self._final_cache[1]
 

@@ -124,12 +124,13 @@ class Attention(_HipModule):
 
     # ---- packed descriptor -------------------------------------------------------------------
     def _build_desc(self):
-        dtype, two, split = R.policy_dtype()
+        dtype, wlevel, split = R.policy_dtype()
         H = self._num_heads
+        two = wlevel >= 3          # proj_q / proj_k: split only under the all-split (x3) policies
         q = R.PackedLinear(self.proj_q.weight, self.proj_q.bias, H, 1, dtype, two)
         k = R.PackedLinear(self.proj_k.weight, self.proj_k.bias, H, 1, dtype, two)
-        v = R.PackedLinear(self.proj_v.weight, self.proj_v.bias, H, 1, dtype, two)
-        o = R.PackedLinear(self.final.weight, self.final.bias, 1, H, dtype, two)
+        v = R.PackedLinear(self.proj_v.weight, self.proj_v.bias, H, 1, dtype, wlevel >= 1)
+        o = R.PackedLinear(self.final.weight, self.final.bias, 1, H, dtype, wlevel >= 1)
         dk, dv = self._qk_channels_per_head, self._v_channels_per_head
         d = L.Attention(q.desc, k.desc, v.desc, o.desc, H, dk, dv, R.pad8(dk), R.pad8(dv),
                         self.proj_q.in_features, self.proj_k.in_features, self.proj_v.in_features,
@@ -200,7 +201,8 @@ class MLP(_HipModule):
         self.dropout = nn.Dropout(dropout_prob)
 
     def _build_desc(self):
-        dtype, two, split = R.policy_dtype()
+        dtype, wlevel, split = R.policy_dtype()
+        two = wlevel >= 2
         f1 = R.PackedLinear(self.fc1.weight, self.fc1.bias, 1, 1, dtype, two)
         f2 = R.PackedLinear(self.fc2.weight, self.fc2.bias, 1, 1, dtype, two)
         d = L.Mlp(f1.desc, f2.desc, self.fc1.in_features, self.fc1.out_features, self.fc2.out_features, dtype,
