@@ -189,6 +189,44 @@ def main():
         nrec = lib.pio_prof_end(ms, fl, by, ln)
         assert nrec > 0, nrec
 
+        # ---- per-stage timing of the three hot-path stages (HIP events on the launch stream, 5 repeats each) ----
+        pio = model.perceiver
+        with P.runtime.precision(args.policy):
+            xin = pio._multi_preprocessor({"__default": x})[0] if not args.hot_path_only else x
+            lat0 = pio._encoder.latents(xin)
+            enc = pio._encoder
+
+            def timed(fn, n=5):
+                fn()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(n):
+                    fn()
+                e1.record()
+                torch.cuda.synchronize()
+                return e0.elapsed_time(e1) / n
+
+            t_cross = timed(lambda: enc.cross_attend(lat0, xin))
+            z1 = enc.cross_attend(lat0, xin)
+            t_sa = timed(lambda: enc.self_attends[0](z1))
+            zf = enc(xin, lat0)
+            qtab_ = pio._output_queries["__default"]._position_encoding.pos_embs
+            qv = torch.broadcast_to(qtab_[None], (B,) + qtab_.shape)
+            t_dec = timed(lambda: pio._decoder(qv, zf))
+
+    # algorithmic work per sample: FLOPs = 2mnk per product; encoder cross-attend bytes =
+    # fp32 input M*C*4 + fp32 latents out N*D*4 (+ 5.9 MB of weights once per batch)
+    enc_bytes = B * (CFG["M"] * CFG["C"] * 4 + CFG["N"] * CFG["D"] * 4) + 5.9e6
+    stages = {
+        "encoder_cross_attend": {"ms": t_cross, "algo_tflops": 6.191e9 * B / (t_cross * 1e-3) / 1e12,
+                                 "algo_gbps": enc_bytes / (t_cross * 1e-3) / 1e9,
+                                 "hbm_frac_of_8TBps": enc_bytes / (t_cross * 1e-3) / 8e12},
+        "self_attend_layer": {"ms": t_sa, "algo_tflops": 7.516e9 * B / (t_sa * 1e-3) / 1e12,
+                              "mfma_frac": 7.516e9 * B / (t_sa * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS,
+                              "x_layers": CFG["L"] * CFG["blocks"]},
+        "decoder_and_final": {"ms": t_dec, "algo_tflops": (12.633e9 + 2.048e9) * B / (t_dec * 1e-3) / 1e12},
+    }
+
     ms_per_step = elapsed / args.steps * 1e3
     value = world * B * args.steps / elapsed
     names = ["gemm_nt_256", "gemm_nt_128_batched", "layernorm_cast", "softmax", "pack", "flash_attn",
@@ -230,7 +268,7 @@ def main():
         "per_gpu": value / world,
         "model_algo_tflops": value * GFLOP_PER_SAMPLE / 1e3,
         "model_mfma_frac": value / world * GFLOP_PER_SAMPLE / 1e3 / MFMA_PEAK_TFLOPS,
-        "roofline": roofline, "kernels": kernels, "parity": parity,
+        "roofline": roofline, "stages": stages, "kernels": kernels, "parity": parity,
     }
     if rank == 0 and world == 1 and args.cpu_sample > 0:
         v, dt = cpu_baseline(params, args.cpu_sample)

@@ -224,6 +224,73 @@ __global__ __launch_bounds__(256) void layernorm_cast_reg_kernel(const float *__
     }
 }
 
+// The same with 8-byte (float2) accesses for even channel counts whose rows are only 8-byte aligned -- the 322-wide
+// encoder input array [B, 3136, 322]: 129 MB at B = 32, the largest single read of the model.
+template <int DT, bool NORM>
+__global__ __launch_bounds__(256) void layernorm_cast_reg2_kernel(const float *__restrict__ x, int64_t stride_b,
+                                                                  int64_t stride_t, int T, int64_t rows, int C,
+                                                                  const float *__restrict__ gamma,
+                                                                  const float *__restrict__ beta, float eps,
+                                                                  typename Op<DT>::T *__restrict__ y,
+                                                                  typename Op<DT>::T *__restrict__ y_lo, int c_pad) {
+    typedef typename Op<DT>::T OT;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef OT OT2 __attribute__((ext_vector_type(2)));
+    constexpr int NV = 16;
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float *xr = x + (row / T) * stride_b + (row % T) * stride_t;
+    OT *yr = y + row * (int64_t)c_pad;
+    OT *ylr = y_lo ? y_lo + row * (int64_t)c_pad : nullptr;
+    f32x2 v[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int i = (j * 64 + lane) * 2;
+        v[j] = (i < C) ? *(const f32x2 *)(xr + i) : (f32x2){0.f, 0.f};
+    }
+    float mean = 0.f, rstd = 1.f;
+    if (NORM) {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) s += v[j][0] + v[j][1];
+        mean = wave_sum(s) / (float)C;
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int i = (j * 64 + lane) * 2;
+            if (i < C) {
+                const float d0 = v[j][0] - mean, d1 = v[j][1] - mean;
+                q += d0 * d0 + d1 * d1;
+            }
+        }
+        rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
+    }
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int i = (j * 64 + lane) * 2;
+        if (i < c_pad) {
+            f32x2 f = {0.f, 0.f};
+            if (i < C) {
+                f = v[j];
+                if (NORM) {
+                    const f32x2 g = *(const f32x2 *)(gamma + i);
+                    const f32x2 b = *(const f32x2 *)(beta + i);
+                    f[0] = (f[0] - mean) * rstd * g[0] + b[0];
+                    f[1] = (f[1] - mean) * rstd * g[1] + b[1];
+                }
+            }
+            OT2 o, l;
+            o[0] = Op<DT>::from_f32(f[0]);
+            o[1] = Op<DT>::from_f32(f[1]);
+            l[0] = Op<DT>::from_f32(f[0] - Op<DT>::to_f32(o[0]));
+            l[1] = Op<DT>::from_f32(f[1] - Op<DT>::to_f32(o[1]));
+            *(OT2 *)(yr + i) = o;
+            if (ylr) *(OT2 *)(ylr + i) = l;
+        }
+    }
+}
+
 int layernorm_cast_launch(const pio_tensor3_t &x, const pio_layernorm_t *ln, void *y, void *y_lo, int c_pad,
                           int dtype, hipStream_t s) {
     if (!x.data || !y) return PIO_E_ARG;
@@ -250,6 +317,19 @@ int layernorm_cast_launch(const pio_tensor3_t &x, const pio_layernorm_t *ln, voi
         if (dtype == PIO_DT_F16) { if (ln) PIO_LNR_LAUNCH(PIO_DT_F16, true); else PIO_LNR_LAUNCH(PIO_DT_F16, false); }
         else                     { if (ln) PIO_LNR_LAUNCH(PIO_DT_BF16, true); else PIO_LNR_LAUNCH(PIO_DT_BF16, false); }
 #undef PIO_LNR_LAUNCH
+        return launch_status();
+    }
+    const bool vec2 = (x.C % 2 == 0) && (((uintptr_t)x.data & 7) == 0) && (x.stride_b % 2 == 0) &&
+                      (x.stride_t % 2 == 0) && (((uintptr_t)y & 3) == 0) && (((uintptr_t)y_lo & 3) == 0) &&
+                      (!ln || ((((uintptr_t)ln->gamma) & 7) == 0 && (((uintptr_t)ln->beta) & 7) == 0));
+    if (vec2 && c_pad <= 2048 && (dtype == PIO_DT_F16 || dtype == PIO_DT_BF16)) {
+#define PIO_LNR2_LAUNCH(DTV, NORMV)                                                                               \
+    hipLaunchKernelGGL((layernorm_cast_reg2_kernel<DTV, NORMV>), dim3(blocks), dim3(256), 0, s, x.data, x.stride_b, \
+                       x.stride_t, x.T, rows, x.C, g, b, eps, (typename Op<DTV>::T *)y,                            \
+                       (typename Op<DTV>::T *)y_lo, c_pad)
+        if (dtype == PIO_DT_F16) { if (ln) PIO_LNR2_LAUNCH(PIO_DT_F16, true); else PIO_LNR2_LAUNCH(PIO_DT_F16, false); }
+        else                     { if (ln) PIO_LNR2_LAUNCH(PIO_DT_BF16, true); else PIO_LNR2_LAUNCH(PIO_DT_BF16, false); }
+#undef PIO_LNR2_LAUNCH
         return launch_status();
     }
     if (dtype == PIO_DT_F16) {
@@ -350,14 +430,142 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const SoftmaxParams p
     }
 }
 
+// Register-resident variant: one wave per row, the row (<= NV4*256 scores, Tk % 4 == 0) is read from memory ONCE
+// with 16-byte loads and kept in VGPRs for the max / sum / normalise steps (the generic kernel above re-reads it three
+// times through L1/L2).  Loads are unconditional from clamped addresses -- a per-element "load or constant" select
+// makes hipcc branch around every load and drain vmcnt per element -- and masking is a register select afterwards.
+// PLAIN = no mask / bias / lo / probability outputs (the common case): nothing but the loads, exp and stores.
+template <int DT, int NV4, bool PLAIN>
+__global__ __launch_bounds__(256) void softmax_rows_reg_kernel(const SoftmaxParams p) {
+    typedef typename Op<DT>::T OT;
+    typedef typename Op<DT>::V4 OV4;
+    const int lane = threadIdx.x & 63;
+    const int64_t rows = (int64_t)p.B * p.H * p.Tq;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int i = (int)(row % p.Tq);
+    const int b = (int)(row / ((int64_t)p.H * p.Tq));
+    const float *s = p.S + row * p.lds;
+    OT *pr = (OT *)p.P + row * p.ldp;
+    const int last4 = p.Tk - 4;  // Tk % 4 == 0: the last aligned float4 of the row
+
+    f32x4 v[NV4];
+#pragma unroll
+    for (int j = 0; j < NV4; ++j) {
+        const int k = (j * 64 + lane) * 4;
+        const f32x4 x = *(const f32x4 *)(s + (k <= last4 ? k : last4));
+        v[j] = x;
+    }
+    bool qok = true;
+    if (!PLAIN) {
+        const float *bi = p.bias ? p.bias + row * (int64_t)p.Tk : nullptr;
+        const uint8_t *km = p.kv_mask ? p.kv_mask + (int64_t)b * p.Tk : nullptr;
+        const uint8_t *fm = p.full_mask ? p.full_mask + ((int64_t)b * p.Tq + i) * p.Tk : nullptr;
+        qok = p.q_mask ? p.q_mask[(int64_t)b * p.Tq + i] != 0 : true;
+#pragma unroll
+        for (int j = 0; j < NV4; ++j) {
+            const int k = (j * 64 + lane) * 4;
+            const int kc = k <= last4 ? k : last4;
+            if (bi) {
+                const f32x4 bv = *(const f32x4 *)(bi + kc);
+                v[j] += bv;
+            }
+            uint32_t mk = 0x01010101u;
+            if (km) mk &= *(const uint32_t *)(km + kc);
+            if (fm) {
+                const uint32_t f = *(const uint32_t *)(fm + kc);
+                mk = ((mk & 0xffu) && (f & 0xffu) ? 1u : 0u) | ((mk & 0xff00u) && (f & 0xff00u) ? 0x100u : 0u) |
+                     ((mk & 0xff0000u) && (f & 0xff0000u) ? 0x10000u : 0u) |
+                     ((mk & 0xff000000u) && (f & 0xff000000u) ? 0x1000000u : 0u);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (!qok || !((mk >> (8 * e)) & 0xffu)) v[j][e] = -INFINITY;
+        }
+    }
+    float m = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < NV4; ++j) {
+        const int k = (j * 64 + lane) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float x = (k < p.Tk) ? v[j][e] * p.scale : -INFINITY;
+            v[j][e] = x;
+            m = fmaxf(m, x);
+        }
+    }
+    m = wave_max(m);
+    const bool any = m > -INFINITY;
+    const float msafe = any ? m : 0.f;
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV4; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float ex = __expf(v[j][e] - msafe);   // exp(-inf) = 0 for masked / out-of-range entries
+            v[j][e] = ex;
+            sum += ex;
+        }
+    sum = wave_sum(sum);
+    const float inv = any ? 1.f / sum : 0.f;
+    OT *plr = (!PLAIN && p.P_lo) ? (OT *)p.P_lo + row * p.ldp : nullptr;
+    float *po = (!PLAIN && p.probs) ? p.probs + row * (int64_t)p.Tk : nullptr;
+    const float uni = 1.f / (float)p.Tk;
+#pragma unroll
+    for (int j = 0; j < NV4; ++j) {
+        const int k = (j * 64 + lane) * 4;
+        if (k < (int)p.ldp) {     // ldp % 4 == 0; columns [Tk, ldp) get exact zeros
+            OV4 h, l;
+            f32x4 x;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                x[e] = v[j][e] * inv;
+                h[e] = Op<DT>::from_f32(x[e]);
+                l[e] = Op<DT>::from_f32(x[e] - Op<DT>::to_f32(h[e]));
+            }
+            *(OV4 *)(pr + k) = h;
+            if (plr) *(OV4 *)(plr + k) = l;
+            if (po && k < p.Tk) {
+                if (!any) x = (f32x4){uni, uni, uni, uni};
+                *(f32x4 *)(po + k) = x;
+            }
+        }
+    }
+}
+
 int softmax_rows_launch(const float *S, int64_t lds, void *P, void *P_lo, int64_t ldp, int B, int H, int Tq, int Tk,
                         float scale, const uint8_t *kv_mask, const uint8_t *q_mask, const uint8_t *full_mask,
                         const float *bias, int dtype, float *probs_out, hipStream_t s) {
     if (!S || !P) return PIO_E_ARG;
     if (B <= 0 || H <= 0 || Tq <= 0 || Tk <= 0 || ldp < Tk || lds < Tk) return PIO_E_SHAPE;
+    if (dtype != PIO_DT_F16 && dtype != PIO_DT_BF16) return PIO_E_ARG;
     SoftmaxParams p{S, lds, P, P_lo, ldp, B, H, Tq, Tk, scale, kv_mask, q_mask, full_mask, bias, probs_out};
     const int64_t rows = (int64_t)B * H * Tq;
     ProfScope prof(PROF_SOFTMAX, 0.0, (double)rows * (4.0 * Tk + (P_lo ? 4.0 : 2.0) * ldp), s);
+    const bool plain = !kv_mask && !q_mask && !full_mask && !bias && !P_lo && !probs_out;
+    const bool vec4 = (Tk % 4 == 0) && (ldp % 4 == 0) && (lds % 4 == 0) && (((uintptr_t)S & 15) == 0) &&
+                      (((uintptr_t)P & 7) == 0) && (((uintptr_t)P_lo & 7) == 0) && (((uintptr_t)bias & 15) == 0) &&
+                      (((uintptr_t)probs_out & 15) == 0) && (((uintptr_t)kv_mask & 3) == 0) &&
+                      (((uintptr_t)full_mask & 3) == 0);
+    if (vec4 && ldp <= 16 * 256) {
+        const unsigned blocks = (unsigned)((rows + 3) / 4);
+#define PIO_SMR2(DTV, NVV)                                                                                         \
+    do {                                                                                                           \
+        if (plain) hipLaunchKernelGGL((softmax_rows_reg_kernel<DTV, NVV, true>), dim3(blocks), dim3(256), 0, s, p); \
+        else hipLaunchKernelGGL((softmax_rows_reg_kernel<DTV, NVV, false>), dim3(blocks), dim3(256), 0, s, p);      \
+    } while (0)
+#define PIO_SMR(NVV)                                             \
+    do {                                                         \
+        if (dtype == PIO_DT_F16) PIO_SMR2(PIO_DT_F16, NVV);      \
+        else PIO_SMR2(PIO_DT_BF16, NVV);                         \
+    } while (0)
+        if (ldp <= 2 * 256) PIO_SMR(2);
+        else if (ldp <= 8 * 256) PIO_SMR(8);
+        else PIO_SMR(16);
+#undef PIO_SMR
+#undef PIO_SMR2
+        return launch_status();
+    }
     if (Tk <= 2048) {
         const unsigned blocks = (unsigned)((rows + 3) / 4);
         if (dtype == PIO_DT_F16) hipLaunchKernelGGL((softmax_rows_kernel<PIO_DT_F16, 1>), dim3(blocks), dim3(256), 0, s, p);
