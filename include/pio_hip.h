@@ -78,6 +78,8 @@ typedef struct pio_attention_t {
     int32_t act_split; /* 1: activations are carried as hi+lo pairs too (3 MFMA sweeps, ~fp32 products) */
     pio_linear_t qk;   /* optional (w_hi may be NULL): proj_q and proj_k stacked along the output rows
                           [q rows | k rows], used as ONE GEMM when inputs_q and inputs_k are the same tensor */
+    pio_linear_t qkv;  /* optional (w_hi may be NULL): [q rows | k rows | v rows] for self-attention with
+                          dkp == dvp == 128: one GEMM, V consumed row-major by the fused attention kernel */
 } pio_attention_t;
 
 /* MLP (transformer_primitives.py:183-216) */

@@ -127,6 +127,28 @@ static int attention_core(const pio_attention_t &a, Pair xq, bool q_bcast, Pair 
     const int64_t hdk = (int64_t)H * a.dkp, ldo = (int64_t)H * a.dvp, tkp = pad8(Tk);
     const int Bq = q_bcast ? 1 : B;
 
+    // 0: the fully fused self-attention form: ONE GEMM over the stacked [q | k | v] weight image, then the fused
+    //    attention kernel reading V row-major (transposed LDS reads).  Needs: same input for q, k and v, single-
+    //    sweep operands everywhere, 128-wide heads, nothing that wants the score matrix, and the q16 | k16 | vt16
+    //    scratch regions adjacent so that they form one [rows, 3*H*128] matrix.
+    {
+        const size_t third = (size_t)B * Tq * hdk * 2;
+        const bool fuse_qkv = a.qkv.w_hi && !a.qkv.w_lo && !a.act_split && !q_bcast && xq.hi == xk.hi &&
+                              xk.hi == xv.hi && Tq == Tk && a.dkp == 128 && a.dvp == 128 && a.qkv.n == 3 * hdk &&
+                              !kv_mask && !q_mask && !full_mask && !attention_bias && !probs_out &&
+                              (char *)w.k16.hi == (char *)w.q16.hi + third &&
+                              (char *)w.vt16.hi == (char *)w.k16.hi + third;
+        if (fuse_qkv) {
+            const int64_t ld3 = 3 * hdk;
+            PIO_TRY(linear_fwd(a.qkv, a.dtype, xq, (int64_t)B * Tq, w.q16.hi, nullptr, false, 0, ld3, 0, nullptr, s));
+            const char *base = (const char *)w.q16.hi;
+            PIO_TRY(flash_attention_launch(a.dtype, 128, 128, a.dk, base, base + hdk * 2, base + 2 * hdk * 2,
+                                           w.o16.hi, B, H, Tq, Tk, ld3, ld3, ld3, ldo, (int64_t)Tq * ld3,
+                                           (int64_t)Tk * ld3, (int64_t)Tk * ld3, (int64_t)Tq * ldo, true, s));
+            return linear_fwd(a.o, a.dtype, w.o16, (int64_t)B * Tq, out, nullptr, true, a.out, a.out, 0, res, s);
+        }
+    }
+
     // 1/2: Q and K projections (transformer_primitives.py:93-94), head-padded columns.  When both read the same
     //      16-bit input (self-attention) they are ONE GEMM over the stacked [q rows | k rows] weight image: the
     //      q16 / k16 scratch regions are adjacent, the fused output uses them as one [rows, 2*H*dkp] matrix.
@@ -173,7 +195,7 @@ static int attention_core(const pio_attention_t &a, Pair xq, bool q_bcast, Pair 
     if (fused) {
         PIO_TRY(flash_attention_launch(a.dtype, a.dkp, a.dvp, a.dk, w.q16.hi, k_hi, w.vt16.hi, w.o16.hi, B, H, Tq,
                                        Tk, ldq, ldq, tkp, ldo, q_bcast ? 0 : (int64_t)Tq * ldq, (int64_t)Tk * ldq,
-                                       ldo * tkp, (int64_t)Tq * ldo, s));
+                                       ldo * tkp, (int64_t)Tq * ldo, false, s));
         return linear_fwd(a.o, a.dtype, w.o16, (int64_t)B * Tq, out, nullptr, true, a.out, a.out, 0, res, s);
     }
     // 4: S[b,h] = Q[b,h] K[b,h]^T (transformer_primitives.py:138), fp32 scores

@@ -29,11 +29,15 @@ struct FlashParams {
 
 static __device__ __attribute__((aligned(16))) uint32_t g_zero_chunk_f[4] = {0, 0, 0, 0};
 
-template <int DT, int DK, int DV>
+// VROW = true (DV = 128 only): V is consumed ROW-major ([keys][H*dv], the layout a plain projection GEMM writes, so
+// Q | K | V come out of ONE fused GEMM) through transposed LDS reads; VROW = false: V^T [dv][keys] as before.
+template <int DT, int DK, int DV, bool VROW>
 __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const FlashParams p) {  // 2 workgroups per CU
     typedef typename Op<DT>::T T;
     typedef typename Op<DT>::V8 V8;
     typedef typename Op<DT>::V4 V4;
+    typedef short tr4 __attribute__((__vector_size__(4 * sizeof(short))));
+    static_assert(!VROW || DV == 128, "row-major V path is written for 256-byte V rows");
     constexpr int KT = 64;                       // keys per tile
     constexpr int K_TILE = KT * DK * 2;          // bytes
     constexpr int V_TILE = DV * KT * 2;          // bytes
@@ -60,7 +64,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const FlashParams p)
 
     const T *Qg = (const T *)p.Q + b * p.sQb + (int64_t)h * DK;
     const T *Kg = (const T *)p.K + b * p.sKb + (int64_t)h * DK;
-    const T *Vg = (const T *)p.VT + b * p.sVb + (int64_t)h * DV * p.ldvt;
+    const T *Vg = (const T *)p.VT + b * p.sVb + (VROW ? (int64_t)h * DV : (int64_t)h * DV * p.ldvt);
     const T *zsrc = (const T *)g_zero_chunk_f;
 
     // ---- Q fragments (B operand): lane holds Q[q0 + r32][16*s + 8*hh + 0..7]
@@ -90,6 +94,20 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const FlashParams p)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                              (__attribute__((address_space(3))) void *)(kb + pc * 1024), 16, 0, 0);
         }
+        if constexpr (VROW) {
+            // row-major V tile [64 keys][DV = 128]: 256-byte rows (16 chunks), a 1-KiB piece = 4 key rows
+            for (int pc = wave; pc < V_PIECES; pc += 4) {
+                const int row = pc * 4 + (lane >> 4);
+                const int slot = lane & 15;
+                const int c = slot ^ (((row & 3) << 2) | ((row >> 2) & 3));
+                int key = k0 + row;
+                key = key < p.Tk ? key : p.Tk - 1;
+                const T *src = Vg + (int64_t)key * p.ldvt + c * 8;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                 (__attribute__((address_space(3))) void *)(vb + pc * 1024), 16, 0,
+                                                 0);
+            }
+        } else
         // V^T tile: rows = dv (128-byte rows, 8 chunks), piece = 8 rows
         for (int pc = wave; pc < V_PIECES; pc += 4) {
             const int row = pc * 8 + (lane >> 3);
@@ -197,9 +215,29 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const FlashParams p)
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
-                    const int g = 8 * t + 4 * s + hh;  // 8-byte granule of keys [4g, 4g+4); second one is g+2
-                    const V4 lo = *(const V4 *)(vrow + ((((g >> 1)) ^ v_swz) << 4) + (g & 1) * 8);
-                    const V4 hi = *(const V4 *)(vrow + ((((g + 2) >> 1) ^ v_swz) << 4) + (g & 1) * 8);
+                    V4 lo, hi;
+                    if constexpr (VROW) {
+                        // V tile is ROW-major [64 keys][DV] (256-byte rows); the fragment is read TRANSPOSED by
+                        // ds_read_b64_tr_b16: per 16-lane group a 4-key x 16-column block, lane 4q+p supplies the
+                        // address of key q / columns 4p..4p+3 and receives its own column of the 4 keys.
+                        // chunk swizzle f(row) = ((row&3)<<2) | ((row>>2)&3) (conflict-free for row and tr reads)
+                        const int q4 = (lane & 15) >> 2, p4 = lane & 3, g1 = (lane >> 4) & 1;
+                        const int chunk = d * 4 + 2 * g1 + (p4 >> 1);
+#pragma unroll
+                        for (int jj = 0; jj < 2; ++jj) {
+                            const int key = 32 * t + 16 * s + 8 * jj + 4 * hh + q4;
+                            const int f = (q4 << 2) | ((hh + 2 * jj) & 3);
+                            const char *a = vb + key * 256 + ((chunk ^ f) << 4) + 8 * (p4 & 1);
+                            const tr4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                                (__attribute__((address_space(3))) tr4 *)a);
+                            if (jj == 0) lo = __builtin_bit_cast(V4, r);
+                            else hi = __builtin_bit_cast(V4, r);
+                        }
+                    } else {
+                        const int g = 8 * t + 4 * s + hh;  // 8-byte granule of keys [4g, 4g+4); second one is g+2
+                        lo = *(const V4 *)(vrow + ((((g >> 1)) ^ v_swz) << 4) + (g & 1) * 8);
+                        hi = *(const V4 *)(vrow + ((((g + 2) >> 1) ^ v_swz) << 4) + (g & 1) * 8);
+                    }
                     V8 vf;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
@@ -234,10 +272,12 @@ bool flash_supported(int dkp, int dvp) {
            (dkp == 32 && dvp == 160);
 }
 
+// v_rowmajor: VT points at V [B][Tk][.. h*dvp ..] (row stride ldvt) instead of V^T [B][H*dvp][Tk]; dvp == 128 only.
 int flash_attention_launch(int dtype, int dkp, int dvp, int dk_logical, const void *Q, const void *K, const void *VT,
                            void *O, int B, int H, int Tq, int Tk, int64_t ldq, int64_t ldk, int64_t ldvt, int64_t ldo,
-                           int64_t sQb, int64_t sKb, int64_t sVb, int64_t sOb, hipStream_t s) {
+                           int64_t sQb, int64_t sKb, int64_t sVb, int64_t sOb, bool v_rowmajor, hipStream_t s) {
     if (!flash_supported(dkp, dvp)) return PIO_E_SHAPE;
+    if (v_rowmajor && !(dkp == 128 && dvp == 128)) return PIO_E_SHAPE;
     if (!Q || !K || !VT || !O) return PIO_E_ARG;
     if (B <= 0 || H <= 0 || Tq <= 0 || Tk <= 0 || (int64_t)B * H * ((Tq + 127) / 128) > 0x7fffffffLL) return PIO_E_SHAPE;
     if ((ldq % 8) || (ldk % 8) || (ldvt % 8) || (ldo % 4) || (sQb % 8) || (sKb % 8) || (sVb % 8) || (sOb % 4))
@@ -249,13 +289,16 @@ int flash_attention_launch(int dtype, int dkp, int dvp, int dk_logical, const vo
     dim3 grid((unsigned)(nqt * B * H), 1, 1), block(256, 1, 1);
     ProfScope prof(PROF_FLASH, 2.0 * B * H * (double)Tq * Tk * (dkp + dvp),
                    2.0 * B * H * ((double)Tq * (dkp + dvp) + (double)Tk * (dkp + dvp)), s);
-#define PIO_FLASH(DTV, DKV, DVV) hipLaunchKernelGGL((flash_attn_kernel<DTV, DKV, DVV>), grid, block, 0, s, p)
+#define PIO_FLASH(DTV, DKV, DVV) hipLaunchKernelGGL((flash_attn_kernel<DTV, DKV, DVV, false>), grid, block, 0, s, p)
 #define PIO_FLASH_DT(DKV, DVV)                                         \
     do {                                                               \
         if (dtype == PIO_DT_F16) PIO_FLASH(PIO_DT_F16, DKV, DVV);      \
         else PIO_FLASH(PIO_DT_BF16, DKV, DVV);                         \
     } while (0)
-    if (dkp == 128 && dvp == 128) PIO_FLASH_DT(128, 128);
+    if (v_rowmajor) {
+        if (dtype == PIO_DT_F16) hipLaunchKernelGGL((flash_attn_kernel<PIO_DT_F16, 128, 128, true>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((flash_attn_kernel<PIO_DT_BF16, 128, 128, true>), grid, block, 0, s, p);
+    } else if (dkp == 128 && dvp == 128) PIO_FLASH_DT(128, 128);
     else if (dkp == 64 && dvp == 64) PIO_FLASH_DT(64, 64);
     else if (dkp == 32 && dvp == 32) PIO_FLASH_DT(32, 32);
     else PIO_FLASH_DT(32, 160);

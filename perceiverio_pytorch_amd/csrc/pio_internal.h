@@ -93,7 +93,7 @@ int softmax_rows_launch(const float *S, int64_t lds, void *P, void *P_lo, int64_
 bool flash_supported(int dkp, int dvp);
 int flash_attention_launch(int dtype, int dkp, int dvp, int dk_logical, const void *Q, const void *K, const void *VT,
                            void *O, int B, int H, int Tq, int Tk, int64_t ldq, int64_t ldk, int64_t ldvt, int64_t ldo,
-                           int64_t sQb, int64_t sKb, int64_t sVb, int64_t sOb, hipStream_t s);
+                           int64_t sQb, int64_t sKb, int64_t sVb, int64_t sOb, bool v_rowmajor, hipStream_t s);
 int pack_linear_launch(const float *w, const float *bias, int out, int in, int64_t ldw, int row_heads,
                        int col_heads, void *dst_hi, void *dst_lo, float *dst_bias, int dst_row0, int k_pad,
                        int dtype, hipStream_t s);

@@ -141,6 +141,14 @@ class Attention(_HipModule):
                                H, dtype, two)
             d.qk = qk.desc
             keep.append(qk)
+            # q | k | v in one image: usable when no projection needs a second sweep (plain 1-sweep policy) and
+            # the fused attention kernel can read V row-major (per-head widths 128 / 128)
+            if (wlevel == 0 and self.proj_v.in_features == self.proj_q.in_features and R.pad8(dk) == 128
+                    and R.pad8(dv) == 128):
+                qkv = R.PackedStack([(self.proj_q.weight, self.proj_q.bias), (self.proj_k.weight, self.proj_k.bias),
+                                     (self.proj_v.weight, self.proj_v.bias)], H, dtype, False)
+                d.qkv = qkv.desc
+                keep.append(qkv)
         return d, keep
 
     def _params(self):

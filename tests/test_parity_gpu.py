@@ -305,6 +305,30 @@ def test_fused_attention_vs_oracle(dev, case, policy):
     _assert_close(y3, ref, TIGHT, what=f"materialised attention {case}")
 
 
+@pytest.mark.parametrize("shape", [(2, 512, 8), (3, 100, 2), (1, 777, 4)])
+def test_fully_fused_self_attention_qkv(dev, shape):
+    """inputs_q is inputs_k is inputs_v, 128-wide heads, 1-sweep policy: ONE q|k|v GEMM + the fused attention kernel
+    reading V row-major through transposed LDS reads.  Checked against the oracle and against the same module under
+    fp16x2s (which takes the separate V^T route)."""
+    from perceiverio_pytorch_amd.transformer_primitives import Attention
+    B, T, H = shape
+    cin = 128
+    p = O.gen_attention("", cin, cin, H * 128, H * 128, cin, seed=T)
+    x = np.random.default_rng(T).standard_normal((B, T, cin)).astype(np.float32)
+    m = Attention(cin, cin, cin, num_heads=H, qk_out_channels=H * 128, v_out_channels=H * 128, output_channels=cin)
+    m.load_state_dict(_sd(p, "cpu"))
+    m = m.to(dev).eval()
+    xt = _t(x, dev)
+    ref = O.attention({k: a.astype(np.float64) for k, a in p.items()}, x.astype(np.float64), x.astype(np.float64),
+                      x.astype(np.float64), H)
+    _policy("fp16")
+    y = m(xt, xt, xt)
+    _assert_close(y, ref, TOL, what=f"fused qkv {shape}")
+    _policy("fp16x2s")
+    y2 = m(xt, xt, xt)
+    _assert_close(y, y2.cpu().numpy(), TOL, what=f"fused qkv vs separate V^T {shape}")
+
+
 @pytest.mark.parametrize("policy", POLICIES)
 @pytest.mark.parametrize("name", MLP)
 def test_mlp_golden(dev, name, policy):
