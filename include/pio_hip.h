@@ -130,6 +130,11 @@ int pio_prof_begin(int32_t max_records);
  * Arrays have PIO_PROF_CLASSES entries (any may be NULL).  Returns the number of records or <0. */
 int pio_prof_end(double *ms, double *flops, double *bytes, int64_t *launches);
 
+/* --- kernel selection of pio_gemm_nt, for tests and A/B benchmarks ------------------------------- */
+/* 0: automatic (default; env PIO_GEMM_TILE gives the initial value), 128: 128x128 tile, 256: 256x256 tile,
+ * 1: persistent 256x128 streaming kernel wherever it is legal.  Returns the previous setting. */
+int pio_gemm_kernel_override(int which);
+
 /* --- weight packing (one-off, after load_state_dict) ------------------------------------------ */
 /* Round a channel count up to the packing granule (8). */
 int32_t pio_pad8(int32_t c);

@@ -85,6 +85,7 @@ SIGNATURES = {
     "pio_prof_begin": (C.c_int, [_i32]),
     "pio_prof_end": (C.c_int, [P(C.c_double), P(C.c_double), P(C.c_double), P(C.c_int64)]),
     "pio_pad8": (_i32, [_i32]),
+    "pio_gemm_kernel_override": (C.c_int, [C.c_int]),
     "pio_packed_weight_bytes": (_sz, [_i32, _i32, _i32, _i32]),
     "pio_pack_linear": (C.c_int, [_vp, _vp, _i32, _i32, _i64, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "pio_layernorm_cast": (C.c_int, [P(Tensor3), P(LayerNorm), _vp, _vp, _i32, _i32, _vp]),

@@ -98,6 +98,8 @@ const char *pio_error_string(int code) {
 
 int32_t pio_pad8(int32_t c) { return pad8(c); }
 
+int pio_gemm_kernel_override(int which) { return gemm_kernel_override(which); }
+
 size_t pio_packed_weight_bytes(int32_t out, int32_t in, int32_t row_heads, int32_t col_heads) {
     if (out <= 0 || in <= 0 || row_heads <= 0 || col_heads <= 0 || out % row_heads || in % col_heads) return 0;
     return (size_t)row_heads * pad8(out / row_heads) * (size_t)col_heads * pad8(in / col_heads) * 2;

@@ -223,6 +223,21 @@ __global__ __launch_bounds__(256) void gemm_nt_128(const GemmParams p) {
     }
 }
 
+// kernel selection override (pio_gemm_kernel_override; initial value from env PIO_GEMM_TILE)
+static int &gemm_kernel_choice() {
+    static int choice = [] {
+        const char *e = getenv("PIO_GEMM_TILE");
+        return e ? atoi(e) : 0;
+    }();
+    return choice;
+}
+int gemm_kernel_override(int which) {
+    int &c = gemm_kernel_choice();
+    const int prev = c;
+    c = which;
+    return prev;
+}
+
 int gemm_nt_launch(const pio_gemm_t &g, hipStream_t s) {
     if (!g.A || !g.B || !g.C) return PIO_E_ARG;
     if (g.M <= 0 || g.N <= 0 || g.K <= 0 || g.batch <= 0 || g.nh <= 0) return PIO_E_SHAPE;
@@ -277,15 +292,27 @@ int gemm_nt_launch(const pio_gemm_t &g, hipStream_t s) {
     // Large problems go to the 256x256-tile / 4-slot-ring kernel: enough rows, and an N that fills whole
     // 256-column tiles reasonably (<= 25 % padding).  PIO_GEMM_TILE=128|256 forces one (benchmarks).
     {
-        static const int forced = [] {
-            const char *e = getenv("PIO_GEMM_TILE");
-            return e ? atoi(e) : 0;
-        }();
+        const int forced = gemm_kernel_choice();
         const int tn256 = (p.n_store + 255) / 256, tm256 = (g.M + 255) / 256;
         bool big = g.batch == 1 && g.M >= 1024 && p.n_store >= 256 && (double)tn256 * 256.0 <= 1.25 * p.n_store &&
                    (int64_t)tm256 * tn256 >= 128;
         if (forced == 128) big = false;
         if (forced == 256) big = true;
+        // Persistent 256x128 streaming kernel (epilogue of tile j hidden behind the MFMAs of tile j+1): deep-K flat
+        // problems with about two or more tiles per CU (with fewer there is nothing to hide an epilogue behind and
+        // the 256x256 tile's lower operand traffic wins).  Override 1 forces it wherever it is legal.
+        {
+            const int tn128 = (p.n_store + 127) / 128;
+            bool stream = g.batch == 1 && g.M >= 1024 && p.n_store >= 128 &&
+                          (double)tn128 * 128.0 <= 1.25 * p.n_store && (int64_t)tm256 * tn128 >= 448;
+            if (forced == 1) stream = true;
+            if (forced == 128 || forced == 256) stream = false;
+            if (stream && gemm_stream_ok(p, g.batch)) {
+                ProfScope prof(PROF_GEMM_LINEAR, algo_flops, algo_bytes, s);
+                gemm_stream_launch(p, g.dtype, g.batch, s);
+                return launch_status();
+            }
+        }
         if (big) {
             ProfScope prof(PROF_GEMM_LINEAR, algo_flops, algo_bytes, s);  // class 0 == kernel gemm_nt_256
             p.tiles_n = tn256;

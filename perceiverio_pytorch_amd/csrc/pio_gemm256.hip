@@ -20,6 +20,20 @@ namespace pio {
 
 static __device__ __attribute__((aligned(16))) uint32_t g_zero256[4] = {0, 0, 0, 0};
 
+#ifdef PIO_GEMM_STAMPS
+// Dev-only phase stamps (tools/gemm_stamps.py --build makes a private copy of the library with this flag; the shipped
+// library never has it): wave 0 of tile 0 records s_memtime at the phase edges, g_epi_mode selects an epilogue
+// ablation (1: no global stores, 2: registers -> global without the LDS pass, 3: no epilogue).
+__device__ unsigned long long g_stamps[8];
+__device__ int g_epi_mode;
+#define PIO_STAMP(i)                                                                                  \
+    do {                                                                                              \
+        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_stamps[i] = __builtin_readcyclecounter(); \
+    } while (0)
+#else
+#define PIO_STAMP(i)
+#endif
+
 constexpr int L_BM = 256, L_BN = 256, L_BK = 32, L_STAGES = 4;
 constexpr int L_OP = L_BM * L_BK * 2;  // 16 KiB per operand per stage
 constexpr int L_STAGE = 2 * L_OP;      // 32 KiB
@@ -128,6 +142,7 @@ __global__ __launch_bounds__(512) void gemm_nt_256(const GemmParams p) {
         }
     };
 
+    PIO_STAMP(0);
 #pragma unroll
     for (int t = 0; t < AHEAD; ++t)
         if (t < nk) stage(t);
@@ -144,6 +159,7 @@ __global__ __launch_bounds__(512) void gemm_nt_256(const GemmParams p) {
         V8 af[8], bf[4];
         wait_vm_tiles<0>(nk - 1 < AHEAD - 1 ? nk - 1 : AHEAD - 1);
         __builtin_amdgcn_s_barrier();  // tile 0 visible to everyone
+        PIO_STAMP(1);
         if (wr == 1) __builtin_amdgcn_s_barrier();
         for (int kt = 0; kt < nk; ++kt) {
             const int rem = nk - 2 - kt;
@@ -199,9 +215,35 @@ __global__ __launch_bounds__(512) void gemm_nt_256(const GemmParams p) {
     const int n0 = tile_n * L_BN + lane * 4;
     const bool ncol = n0 < p.n_store;
     const f32x4 bias_n = ncol ? load_bias4<DT>(p, n0) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    // Barriers here order LDS accesses only (raw s_barrier behind lgkmcnt(0)): __syncthreads() would also drain
+    // vmcnt, i.e. make every wave wait for the HBM stores (and residual loads) of the previous half to COMPLETE
+    // before the next half may start -- measured with in-kernel stamps: 26k of a tile's 79k cycles.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (all operand DMA has long landed; keeps the ring quiescent)
+    PIO_STAMP(2);
+#ifdef PIO_GEMM_STAMPS
+    const int epi_mode = g_epi_mode;
+    if (epi_mode == 3) return;
+    if (epi_mode == 2) {
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const int nn = tile_n * L_BN + wc * 64 + ni * 16 + (lane >> 4) * 4;
+            const f32x4 bb = nn < p.n_store ? load_bias4<DT>(p, nn) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi) {
+                const int m = tile_m * L_BM + wr * 128 + mi * 16 + (lane & 15);
+                if (m < p.M && nn < p.n_store) epilogue_store4<DT>(p, coffz, m, nn, acc[mi][ni], bb);
+            }
+        }
+        PIO_STAMP(3);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PIO_STAMP(4);
+        return;
+    }
+#endif
 #pragma unroll 1
     for (int h = 0; h < 2; ++h) {
-        __syncthreads();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
         if (wr == h) {
 #pragma unroll
             for (int mi = 0; mi < 8; ++mi) {
@@ -213,7 +255,8 @@ __global__ __launch_bounds__(512) void gemm_nt_256(const GemmParams p) {
                 }
             }
         }
-        __syncthreads();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
         if (ncol) {
 #pragma unroll 4
             for (int it = 0; it < 16; ++it) {
@@ -221,12 +264,31 @@ __global__ __launch_bounds__(512) void gemm_nt_256(const GemmParams p) {
                 const int m = tile_m * L_BM + h * 128 + ml;
                 if (m < p.M) {
                     const f32x4 v = *(const f32x4 *)(cs + ml * L_BN + ((lane ^ (ml & 15)) << 2));
+#ifdef PIO_GEMM_STAMPS
+                    if (epi_mode == 1) {
+                        if (v[0] == 1.2345e33f) epilogue_store4<DT>(p, coffz, m, n0, v, bias_n);
+                        continue;
+                    }
+#endif
                     epilogue_store4<DT>(p, coffz, m, n0, v, bias_n);
                 }
             }
         }
     }
+    PIO_STAMP(3);
+#ifdef PIO_GEMM_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PIO_STAMP(4);
+#endif
 }
+
+#ifdef PIO_GEMM_STAMPS
+extern "C" int pio_debug_gemm_stamps(unsigned long long *out8, int epi_mode) {
+    if (out8 && hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_stamps), sizeof(g_stamps)) != hipSuccess) return 1;
+    if (epi_mode >= 0 && hipMemcpyToSymbol(HIP_SYMBOL(g_epi_mode), &epi_mode, sizeof(int)) != hipSuccess) return 2;
+    return 0;
+}
+#endif
 
 void gemm256_launch(const GemmParams &p, int dtype, bool attn, int tiles_m, int tiles_n, int batch, hipStream_t s) {
     static const int var = [] {

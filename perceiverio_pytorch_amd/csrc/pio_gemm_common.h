@@ -122,4 +122,8 @@ __device__ __forceinline__ f32x4 load_bias4(const GemmParams &p, int n0) {
 // 256x256-tile kernel (pio_gemm256.hip); `attn` only selects the kernel-name tag.
 void gemm256_launch(const GemmParams &p, int dtype, bool attn, int tiles_m, int tiles_n, int batch, hipStream_t s);
 
+// persistent 256x128-tile streaming kernel (pio_gemm_stream.hip)
+bool gemm_stream_ok(const GemmParams &p, int batch);
+void gemm_stream_launch(const GemmParams &p, int dtype, int batch, hipStream_t s);
+
 }  // namespace pio

@@ -85,6 +85,7 @@ struct ProfScope {
 
 // ---- internal launchers (defined in the .hip files) ---------------------------------------------
 int gemm_nt_launch(const pio_gemm_t &g, hipStream_t s);
+int gemm_kernel_override(int which);  // 0 auto, 128, 256, 1 = streaming; returns the previous choice
 int layernorm_cast_launch(const pio_tensor3_t &x, const pio_layernorm_t *ln, void *y, void *y_lo, int c_pad,
                           int dtype, hipStream_t s);
 int softmax_rows_launch(const float *S, int64_t lds, void *P, void *P_lo, int64_t ldp, int B, int H, int Tq, int Tk,

@@ -138,6 +138,80 @@ def test_gemm_nt(dev, shape, dt):
     assert err <= tol, f"gemm {shape} {dt}: {err:.3e}"
 
 
+STREAM_SHAPES = [
+    # M, N, K, batch, bias, act, residual, out_f32, lo_weights, lo_out, force   (alpha = 1 with a residual)
+    (16384, 1024, 1024, 1, 1, 0, False, False, False, False, False),  # 512 tiles: 2 per workgroup, 16-bit out
+    (16384, 1024, 1024, 1, 1, 0, True, True, False, False, False),    # residual preloaded into the accumulators
+    (4100, 3000, 1088, 1, 1, 1, False, False, False, False, True),    # ragged M / N, 17 K steps, GELU, uneven lists
+    (3000, 520, 1024, 1, 1, 0, True, True, True, False, True),        # two K sweeps (32 steps), 60 tiles on 56 WGs
+    (1024, 256, 1024, 1, 0, 0, False, False, False, True, True),      # hi + lo outputs, no bias, 8 tiles
+    (2048, 256, 1024, 3, 1, 0, False, True, False, False, True),      # batched slices in the tile list
+    (8192, 1024, 4096, 1, 1, 0, False, False, False, False, True),    # long K: 64 steps per tile, 1 tile per WG
+    (2048, 1024, 1024, 1, 1, 1, False, False, False, True, True),     # GELU with hi + lo outputs
+    (16384, 1024, 1024, 1, 0, 0, False, True, False, False, False),   # fp32 out, no bias, no residual
+]
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("shape", STREAM_SHAPES)
+def test_gemm_nt_stream(dev, shape, dt):
+    """The persistent 256x128 streaming kernel (pio_gemm_stream.hip) against torch fp64 on the same operands."""
+    from perceiverio_pytorch_amd import _lib as L
+    lib = L.lib()
+    M, N, K, batch, bias_mode, act, resid, out_f32, lo_w, lo_out, force = shape
+    tdt = torch.float16 if dt == "f16" else torch.bfloat16
+    g = torch.Generator(device="cpu").manual_seed(M * 7 + N + K)
+    A = torch.randn(batch, M, K, generator=g).to(tdt).to(dev)
+    Bm = (torch.randn(batch, N, K, generator=g) / K ** 0.5).to(dev)
+    Bhi = Bm.to(tdt)
+    Blo = (Bm - Bhi.float()).to(tdt)
+    bias = torch.randn(N, generator=g).to(dev)
+    Rm = torch.randn(M, N, generator=g).to(dev)
+    ldc = N if out_f32 else (N + 7) // 8 * 8
+    Cd = torch.full((batch, M, ldc), float("nan"), dtype=torch.float32 if out_f32 else tdt, device=dev)
+    Cl = torch.full_like(Cd, float("nan"))
+    alpha = 1.0 if resid else 0.5
+    gm = L.Gemm()
+    gm.A, gm.B, gm.C = A.data_ptr(), Bhi.data_ptr(), Cd.data_ptr()
+    gm.B_lo = Blo.data_ptr() if lo_w else None
+    gm.C_lo = Cl.data_ptr() if lo_out else None
+    gm.M, gm.N, gm.K = M, N, K
+    gm.lda, gm.ldb, gm.ldc = K, K, ldc
+    gm.batch, gm.nh = batch, 1
+    gm.sAb, gm.sBb, gm.sCb = M * K, N * K, M * ldc
+    gm.bias = bias.data_ptr() if bias_mode else None
+    gm.bias_mode, gm.act, gm.alpha = bias_mode, act, alpha
+    if resid:
+        gm.R, gm.ldr = Rm.data_ptr(), N
+    gm.out_f32, gm.n_store = int(out_f32), ldc
+    gm.dtype = L.PIO_DT_F16 if dt == "f16" else L.PIO_DT_BF16
+    prev = lib.pio_gemm_kernel_override(1 if force else 0)
+    try:
+        L.check(lib.pio_gemm_nt(C.byref(gm), torch.cuda.current_stream().cuda_stream), "pio_gemm_nt")
+        torch.cuda.synchronize()
+    finally:
+        lib.pio_gemm_kernel_override(prev)
+    W = Bhi.double() + (Blo.double() if lo_w else 0)
+    ref = alpha * torch.bmm(A.double(), W.transpose(1, 2))
+    if bias_mode:
+        ref = ref + bias.double()[None, None, :]
+    if act:
+        ref = torch.nn.functional.gelu(ref)
+    if resid:
+        ref = ref + Rm.double()[None]
+    got = Cd.double()
+    if lo_out:
+        got = got + Cl.double()
+    assert torch.isfinite(got[:, :, :N]).all()
+    if not out_f32:
+        assert (Cd[:, :, N:] == 0).all(), "pad columns must be written as zeros"
+    tol = 2e-5 if (out_f32 or lo_out) else (1e-3 if dt == "f16" else 8e-3)
+    if lo_out and dt == "bf16":
+        tol = 1e-4
+    err = ((got[:, :, :N] - ref).abs().max() / ref.abs().max()).item()
+    assert err <= tol, f"stream gemm {shape} {dt}: {err:.3e}"
+
+
 @pytest.mark.parametrize("C_", [322, 1024, 261, 8, 1280])
 @pytest.mark.parametrize("norm", [True, False])
 def test_layernorm_cast(dev, C_, norm):
