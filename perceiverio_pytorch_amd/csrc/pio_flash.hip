@@ -31,8 +31,10 @@ static __device__ __attribute__((aligned(16))) uint32_t g_zero_chunk_f[4] = {0, 
 
 // VROW = true (DV = 128 only): V is consumed ROW-major ([keys][H*dv], the layout a plain projection GEMM writes, so
 // Q | K | V come out of ONE fused GEMM) through transposed LDS reads; VROW = false: V^T [dv][keys] as before.
-template <int DT, int DK, int DV, bool VROW>
-__global__ __launch_bounds__(256, 2) void flash_attn_kernel(const FlashParams p) {  // 2 workgroups per CU
+// NW = waves per workgroup: 4 (128 query rows, two workgroups per CU) or 8 (256 query rows, one workgroup per CU:
+// every staged K / V tile then serves twice the queries, i.e. half the L2 -> LDS traffic per flop).
+template <int DT, int DK, int DV, bool VROW, int NW>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void flash_attn_kernel(const FlashParams p) {
     typedef typename Op<DT>::T T;
     typedef typename Op<DT>::V8 V8;
     typedef typename Op<DT>::V4 V4;
@@ -60,7 +62,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const FlashParams p)
     if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
     const int qt = bid % p.nqt, bh = bid / p.nqt;
     const int b = bh / p.H, h = bh % p.H;
-    const int q0 = qt * 128 + wave * 32;
+    const int q0 = qt * (NW * 32) + wave * 32;
 
     const T *Qg = (const T *)p.Q + b * p.sQb + (int64_t)h * DK;
     const T *Kg = (const T *)p.K + b * p.sKb + (int64_t)h * DK;
@@ -84,7 +86,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const FlashParams p)
         char *vb = kb + K_TILE;
         const int k0 = kt * KT;
         // K tile: piece = 64 chunks = 64/KCPR rows
-        for (int pc = wave; pc < K_PIECES; pc += 4) {
+        for (int pc = wave; pc < K_PIECES; pc += NW) {
             const int row = pc * (64 / KCPR) + lane / KCPR;
             const int slot = lane % KCPR;
             const int c = slot ^ ((row / KRPB) & (KCPR - 1));
@@ -96,7 +98,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const FlashParams p)
         }
         if constexpr (VROW) {
             // row-major V tile [64 keys][DV = 128]: 256-byte rows (16 chunks), a 1-KiB piece = 4 key rows
-            for (int pc = wave; pc < V_PIECES; pc += 4) {
+            for (int pc = wave; pc < V_PIECES; pc += NW) {
                 const int row = pc * 4 + (lane >> 4);
                 const int slot = lane & 15;
                 const int c = slot ^ (((row & 3) << 2) | ((row >> 2) & 3));
@@ -109,7 +111,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const FlashParams p)
             }
         } else
         // V^T tile: rows = dv (128-byte rows, 8 chunks), piece = 8 rows
-        for (int pc = wave; pc < V_PIECES; pc += 4) {
+        for (int pc = wave; pc < V_PIECES; pc += NW) {
             const int row = pc * 8 + (lane >> 3);
             const int slot = lane & 7;
             const int c = slot ^ ((row >> 1) & 7);
@@ -283,21 +285,26 @@ int flash_attention_launch(int dtype, int dkp, int dvp, int dk_logical, const vo
     if ((ldq % 8) || (ldk % 8) || (ldvt % 8) || (ldo % 4) || (sQb % 8) || (sKb % 8) || (sVb % 8) || (sOb % 4))
         return PIO_E_ALIGN;
     if (((uintptr_t)Q & 15) || ((uintptr_t)K & 15) || ((uintptr_t)VT & 15) || ((uintptr_t)O & 7)) return PIO_E_ALIGN;
-    const int nqt = (Tq + 127) / 128;
+    // 256-row workgroups when that still gives every CU a workgroup (row-major-V flagship path only)
+    const bool wide = v_rowmajor && Tq >= 256 && (int64_t)B * H * ((Tq + 255) / 256) >= 256;
+    const int nqt = wide ? (Tq + 255) / 256 : (Tq + 127) / 128;
     FlashParams p{Q, K, VT, O, Tq, Tk, H, nqt, ldq, ldk, ldvt, ldo, sQb, sKb, sVb, sOb,
                   1.4426950408889634f / sqrtf((float)dk_logical)};
-    dim3 grid((unsigned)(nqt * B * H), 1, 1), block(256, 1, 1);
+    dim3 grid((unsigned)(nqt * B * H), 1, 1), block(wide ? 512 : 256, 1, 1);
     ProfScope prof(PROF_FLASH, 2.0 * B * H * (double)Tq * Tk * (dkp + dvp),
                    2.0 * B * H * ((double)Tq * (dkp + dvp) + (double)Tk * (dkp + dvp)), s);
-#define PIO_FLASH(DTV, DKV, DVV) hipLaunchKernelGGL((flash_attn_kernel<DTV, DKV, DVV, false>), grid, block, 0, s, p)
+#define PIO_FLASH(DTV, DKV, DVV) hipLaunchKernelGGL((flash_attn_kernel<DTV, DKV, DVV, false, 4>), grid, block, 0, s, p)
 #define PIO_FLASH_DT(DKV, DVV)                                         \
     do {                                                               \
         if (dtype == PIO_DT_F16) PIO_FLASH(PIO_DT_F16, DKV, DVV);      \
         else PIO_FLASH(PIO_DT_BF16, DKV, DVV);                         \
     } while (0)
-    if (v_rowmajor) {
-        if (dtype == PIO_DT_F16) hipLaunchKernelGGL((flash_attn_kernel<PIO_DT_F16, 128, 128, true>), grid, block, 0, s, p);
-        else hipLaunchKernelGGL((flash_attn_kernel<PIO_DT_BF16, 128, 128, true>), grid, block, 0, s, p);
+    if (v_rowmajor && wide) {
+        if (dtype == PIO_DT_F16) hipLaunchKernelGGL((flash_attn_kernel<PIO_DT_F16, 128, 128, true, 8>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((flash_attn_kernel<PIO_DT_BF16, 128, 128, true, 8>), grid, block, 0, s, p);
+    } else if (v_rowmajor) {
+        if (dtype == PIO_DT_F16) hipLaunchKernelGGL((flash_attn_kernel<PIO_DT_F16, 128, 128, true, 4>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((flash_attn_kernel<PIO_DT_BF16, 128, 128, true, 4>), grid, block, 0, s, p);
     } else if (dkp == 128 && dvp == 128) PIO_FLASH_DT(128, 128);
     else if (dkp == 64 && dvp == 64) PIO_FLASH_DT(64, 64);
     else if (dkp == 32 && dvp == 32) PIO_FLASH_DT(32, 32);

@@ -379,7 +379,8 @@ def test_fused_attention_vs_oracle(dev, case, policy):
     _assert_close(y3, ref, TIGHT, what=f"materialised attention {case}")
 
 
-@pytest.mark.parametrize("shape", [(2, 512, 8), (3, 100, 2), (1, 777, 4)])
+@pytest.mark.parametrize("shape", [(2, 512, 8), (3, 100, 2), (1, 777, 4),
+                                   (16, 600, 8)])  # enough (batch, head, q-tile)s for the 256-row workgroups
 def test_fully_fused_self_attention_qkv(dev, shape):
     """inputs_q is inputs_k is inputs_v, 128-wide heads, 1-sweep policy: ONE q|k|v GEMM + the fused attention kernel
     reading V row-major through transposed LDS reads.  Checked against the oracle and against the same module under
