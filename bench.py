@@ -14,7 +14,7 @@ with B = 32 per GPU.  Every decoder row is computed (as the reference does); the
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (one rank per GPU, RCCL)
 
 Rank 0 prints ONE JSON line.  Extra objects:
-  roofline     -- the dominant kernel (gemm_nt_256, the weight GEMMs of the latent stack): ALGORITHMIC flops / device
+  roofline     -- the dominant kernel (gemm_nt_stream, the weight GEMMs of the latent stack): ALGORITHMIC flops / device
                   time measured with HIP events around every launch of that kernel in an instrumented repeat of the
                   step; `traffic` = HBM bytes per launch from the committed PMC profile (profiles/traffic.json)
   cpu_baseline -- the numpy oracle ("port") of the hot path timed on this host's cores on a bounded sample
@@ -181,7 +181,7 @@ def main():
         L.check(lib.pio_prof_begin(4096 * nprof), "pio_prof_begin")
         for _ in range(nprof):
             step()
-        NCLS = 7
+        NCLS = 8  # PIO_PROF_CLASSES
         ms = (C.c_double * NCLS)()
         fl = (C.c_double * NCLS)()
         by = (C.c_double * NCLS)()
@@ -230,7 +230,7 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = world * B * args.steps / elapsed
     names = ["gemm_nt_256", "gemm_nt_128_batched", "layernorm_cast", "softmax", "pack", "flash_attn",
-             "gemm_nt_128_flat"]
+             "gemm_nt_128_flat", "gemm_nt_stream"]
     kernels = {}
     for i, nm in enumerate(names):
         if ln[i]:
@@ -238,20 +238,22 @@ def main():
                            "avg_us": ms[i] / ln[i] * 1e3,
                            "algo_tflops": (fl[i] / (ms[i] * 1e-3) / 1e12) if fl[i] else None,
                            "algo_gbps": by[i] / (ms[i] * 1e-3) / 1e9}
-    g = kernels["gemm_nt_256"]
+    # the dominant kernel: the persistent streaming GEMM (class 7) carries the weight GEMMs of the latent stack
+    dom = 7 if ln[7] else 0
+    g = kernels[names[dom]]
     # HBM traffic of that kernel per launch: PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes of
     # this same command, gfx950 correction of MI355X_MICROARCH.md) condensed into profiles/traffic.json
     traffic = None
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-            traffic = json.load(f)["pio::gemm_nt_256"]["bytes_per_launch"]
+            traffic = json.load(f)["pio::" + names[dom]]["bytes_per_launch"]
     except Exception:  # noqa: BLE001  (no committed profile yet)
         traffic = None
-    roofline = {"kernel": "pio::gemm_nt_256 (weight GEMMs of the latent stack: QK / out / fc1 / fc2 projections)",
+    roofline = {"kernel": f"pio::{names[dom]} (weight GEMMs of the latent stack: fused q|k|v, out, fc1, fc2 projections)",
                 "bound": "mfma", "achieved": g["algo_tflops"], "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": g["algo_tflops"] / MFMA_PEAK_TFLOPS, "traffic": traffic,
                 "avg_launch_us": g["avg_us"], "launches_per_step": g["launches_per_step"],
-                "algo_flops_per_launch": fl[0] / ln[0], "algo_bytes_per_launch": by[0] / ln[0]}
+                "algo_flops_per_launch": fl[dom] / ln[dom], "algo_bytes_per_launch": by[dom] / ln[dom]}
 
     workload = ("imagenet224 ClassificationPerceiver (conv+Fourier prep -> encoder 3136x322->512x1024, 8x6 SA -> decoder "
                 "1000 queries -> final Linear), all rows computed")

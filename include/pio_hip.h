@@ -120,9 +120,9 @@ int pio_arch_ok(void);
 const char *pio_error_string(int code);
 
 /* --- per-launch timing for benchmarks (NOT thread-safe, off by default) ------------------------ */
-/* classes: 0 gemm_nt_256 (weight GEMMs), 1 batched gemm_nt_128, 2 layernorm/cast, 3 softmax, 4 pack,
- *          5 fused attention, 6 flat gemm_nt_128 */
-#define PIO_PROF_CLASSES 7
+/* classes: 0 gemm_nt_256, 1 batched gemm_nt_128, 2 layernorm/cast, 3 softmax, 4 pack, 5 fused attention,
+ *          6 flat gemm_nt_128, 7 gemm_nt_stream (persistent streaming kernel: the latent stack's weight GEMMs) */
+#define PIO_PROF_CLASSES 8
 /* Start recording a HIP-event pair around every kernel launch (up to max_records launches). */
 int pio_prof_begin(int32_t max_records);
 /* Stop, wait for the recorded launches and sum per class: device milliseconds, ALGORITHMIC flops

@@ -269,6 +269,8 @@ int gemm_nt_launch(const pio_gemm_t &g, hipStream_t s) {
     p.sAb = g.sAb; p.sAh = g.sAh; p.sBb = g.sBb; p.sBh = g.sBh; p.sCb = g.sCb; p.sCh = g.sCh;
     p.bias = g.bias; p.bias_mode = g.bias_mode; p.act = g.act; p.alpha = g.alpha;
     p.R = g.R; p.ldr = g.ldr; p.r_stride_b = g.r_stride_b; p.r_rows = g.r_rows_per_batch;
+    // a residual whose batches are contiguous ([B, T, C] with stride_b == T * ld) is one flat [B*T, C] matrix
+    if (p.R && p.r_rows > 0 && p.r_stride_b == (int64_t)p.r_rows * p.ldr) p.r_rows = 0;
     p.out_f32 = g.out_f32;
     p.n_store = g.n_store > g.N ? g.n_store : g.N;
     if (p.n_store > g.ldc) return PIO_E_SHAPE;
@@ -308,7 +310,7 @@ int gemm_nt_launch(const pio_gemm_t &g, hipStream_t s) {
             if (forced == 1) stream = true;
             if (forced == 128 || forced == 256) stream = false;
             if (stream && gemm_stream_ok(p, g.batch)) {
-                ProfScope prof(PROF_GEMM_LINEAR, algo_flops, algo_bytes, s);
+                ProfScope prof(PROF_GEMM_STREAM, algo_flops, algo_bytes, s);
                 gemm_stream_launch(p, g.dtype, g.batch, s);
                 return launch_status();
             }

@@ -67,14 +67,15 @@ static inline int launch_status() {
 
 // ---- optional per-launch timing for bench.py (pio_prof_begin / pio_prof_end); off by default ----------
 enum {
-    PROF_GEMM_LINEAR = 0,  // kernel gemm_nt_256 (the weight GEMMs of the latent stack)
+    PROF_GEMM_LINEAR = 0,  // kernel gemm_nt_256 (large flat GEMMs that do not qualify for the streaming kernel)
     PROF_GEMM_ATTN = 1,    // kernel gemm_nt_128<.,1> (batched products)
     PROF_LAYERNORM = 2,
     PROF_SOFTMAX = 3,
     PROF_PACK = 4,
     PROF_FLASH = 5,
     PROF_GEMM_SMALL = 6,   // kernel gemm_nt_128<.,0> (flat problems too small / ragged for the 256 tile)
-    PROF_CLASSES = 7
+    PROF_GEMM_STREAM = 7,  // kernel gemm_nt_stream (persistent 256x128 tiles: the weight GEMMs of the latent stack)
+    PROF_CLASSES = 8
 };
 struct ProfScope {
     int idx;

@@ -24,7 +24,7 @@ with torch.inference_mode(), P.runtime.precision(pol):
     fn(); torch.cuda.synchronize()
     L.check(lib.pio_prof_begin(4096))
     for _ in range(3): fn()
-    ms = (C.c_double * 7)(); fl = (C.c_double * 7)(); by = (C.c_double * 7)(); ln = (C.c_int64 * 7)()
+    ms = (C.c_double * 8)(); fl = (C.c_double * 8)(); by = (C.c_double * 8)(); ln = (C.c_int64 * 8)()
     lib.pio_prof_end(ms, fl, by, ln)
 for i, n in enumerate(names):
     if ln[i]:
