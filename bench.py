@@ -74,6 +74,23 @@ def parity_check(model, g, dev):
     return float(np.sqrt((d * d).sum()) / np.sqrt((ref * ref).sum())), float(np.abs(d).max() / np.abs(ref).max())
 
 
+def cpu_threads():
+    """Threads the numpy oracle can actually use: the BLAS pool size (threadpoolctl) capped by this process's CPU
+    affinity -- not os.cpu_count(), which reports the whole host even inside a 16-CPU share."""
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    try:
+        from threadpoolctl import threadpool_info
+        pools = [p.get("num_threads", 0) for p in threadpool_info() if p.get("user_api") == "blas"]
+        if pools:
+            return min(avail, max(pools))
+    except Exception:  # noqa: BLE001
+        pass
+    return avail
+
+
 def cpu_baseline(params, sample_b):
     """numpy oracle of the hot path (encoder + decoder) on a [B,3136,322] sample, same parameters."""
     import perceiver_oracle as O
@@ -274,7 +291,7 @@ def main():
     }
     if rank == 0 and world == 1 and args.cpu_sample > 0:
         v, dt = cpu_baseline(params, args.cpu_sample)
-        out["cpu_baseline"] = {"value": v, "unit": "samples/s", "cores": os.cpu_count(), "kind": "port",
+        out["cpu_baseline"] = {"value": v, "unit": "samples/s", "cores": cpu_threads(), "kind": "port",
                                "sample": f"numpy fp32 oracle of the hot path (encoder+decoder, 99.9% of the model's "
                                          f"FLOPs), same parameters, B={args.cpu_sample}, one forward ({dt:.1f} s) after "
                                          f"a B=1 warm-up"}

@@ -157,7 +157,9 @@ __global__ __launch_bounds__(256) void layernorm_cast_kernel(const float *__rest
 // Register-resident variant for the common case (C % 4 == 0, C <= 2048, aligned): each lane keeps its <= 8 float4
 // of the row in VGPRs, so the row is read from memory exactly ONCE (the 3-pass form re-reads it through L1/L2,
 // which showed up as ~1.6x the algorithmic FETCH on the 64 MB latent array).
-template <int DT, bool NORM>
+// NV = float4 per lane (4: rows up to 1024 channels, 8: up to 2048); T == 0 tells the kernel that the rows are evenly
+// spaced (stride_b == T * stride_t), which spares every wave a 64-bit division.
+template <int DT, bool NORM, int NV>
 __global__ __launch_bounds__(256) void layernorm_cast_reg_kernel(const float *__restrict__ x, int64_t stride_b,
                                                                  int64_t stride_t, int T, int64_t rows, int C,
                                                                  const float *__restrict__ gamma,
@@ -165,11 +167,10 @@ __global__ __launch_bounds__(256) void layernorm_cast_reg_kernel(const float *__
                                                                  typename Op<DT>::T *__restrict__ y,
                                                                  typename Op<DT>::T *__restrict__ y_lo, int c_pad) {
     typedef typename Op<DT>::T OT;
-    constexpr int NV = 8;
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
-    const float *xr = x + (row / T) * stride_b + (row % T) * stride_t;
+    const float *xr = T > 0 ? x + (row / T) * stride_b + (row % T) * stride_t : x + row * stride_t;
     OT *yr = y + row * (int64_t)c_pad;
     OT *ylr = y_lo ? y_lo + row * (int64_t)c_pad : nullptr;
     f32x4 v[NV];
@@ -310,12 +311,20 @@ int layernorm_cast_launch(const pio_tensor3_t &x, const pio_layernorm_t *ln, voi
                        x.stride_b, x.stride_t, x.T, rows, x.C, g, b, eps, (typename Op<DTV>::T *)y,                \
                        (typename Op<DTV>::T *)y_lo, c_pad)
     if (vec && c_pad <= 2048 && (dtype == PIO_DT_F16 || dtype == PIO_DT_BF16)) {
-#define PIO_LNR_LAUNCH(DTV, NORMV)                                                                               \
-    hipLaunchKernelGGL((layernorm_cast_reg_kernel<DTV, NORMV>), dim3(blocks), dim3(256), 0, s, x.data, x.stride_b, \
-                       x.stride_t, x.T, rows, x.C, g, b, eps, (typename Op<DTV>::T *)y,                           \
+    const bool even = x.B == 1 || x.stride_b == (int64_t)x.T * x.stride_t;
+    const int t_arg = even ? 0 : x.T;
+#define PIO_LNR_LAUNCH2(DTV, NORMV, NVV)                                                                               \
+    hipLaunchKernelGGL((layernorm_cast_reg_kernel<DTV, NORMV, NVV>), dim3(blocks), dim3(256), 0, s, x.data, x.stride_b, \
+                       x.stride_t, t_arg, rows, x.C, g, b, eps, (typename Op<DTV>::T *)y,                               \
                        (typename Op<DTV>::T *)y_lo, c_pad)
+#define PIO_LNR_LAUNCH(DTV, NORMV)                              \
+    do {                                                        \
+        if (c_pad <= 1024) PIO_LNR_LAUNCH2(DTV, NORMV, 4);      \
+        else PIO_LNR_LAUNCH2(DTV, NORMV, 8);                    \
+    } while (0)
         if (dtype == PIO_DT_F16) { if (ln) PIO_LNR_LAUNCH(PIO_DT_F16, true); else PIO_LNR_LAUNCH(PIO_DT_F16, false); }
         else                     { if (ln) PIO_LNR_LAUNCH(PIO_DT_BF16, true); else PIO_LNR_LAUNCH(PIO_DT_BF16, false); }
+#undef PIO_LNR_LAUNCH2
 #undef PIO_LNR_LAUNCH
         return launch_status();
     }

@@ -53,8 +53,10 @@ constexpr int S_AB = S_BM * S_BK * 2;     // 32 KiB of A per stage
 constexpr int S_BB = S_BN * S_BK * 2;     // 16 KiB of B per stage
 constexpr int S_STAGE = S_AB + S_BB;      // 48 KiB
 constexpr int S_RING = S_NST * S_STAGE;   // 144 KiB
-constexpr int S_BIAS_W = 512;             // per wave: 2 parities x 64 floats
-constexpr int S_SMEM = S_RING + 8 * S_BIAS_W;
+constexpr int S_BIAS_W = 768;             // per wave: 3 slots x 64 floats (bias rows of tiles j, j+1, j+2)
+constexpr int S_TAB_N = 256;            // tile-table entries (32 B each): this workgroup's tile list, decoded once
+constexpr int S_TAB = S_RING + 8 * S_BIAS_W;
+constexpr int S_SMEM = S_TAB + S_TAB_N * 32;
 
 template <int N>
 __device__ __forceinline__ void wait_vm_c() {
@@ -77,6 +79,12 @@ __device__ __forceinline__ void static_for(F &&f) {
         f(std::integral_constant<int, I>{});
         static_for<I + 1, N>(f);
     }
+}
+
+__device__ __forceinline__ int64_t uniform64(int64_t v) {  // a value every lane holds -> scalar registers
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32));
+    return (int64_t)(((uint64_t)hi << 32) | lo);
 }
 
 __device__ __forceinline__ void lds_dma16(const void *src, void *lds) {
@@ -118,16 +126,30 @@ __global__ __launch_bounds__(512) void gemm_nt_stream(const GemmParams p, int ti
     const int team = wave >> 2, wm = wave & 3;  // team doubles as the wave's N half
 
     // ---- this workgroup's tile list: the 8 XCDs each own a contiguous run of tile ids (tile_n fastest), and the
-    // workgroups of an XCD take ids of that run round-robin, so the tiles in flight in one L2 share A / B panels
+    // workgroups of an XCD take ids of that run round-robin, so the tiles in flight in one L2 share A / B panels.
+    // (Walking a run in rounds of 4 x 8 tiles instead -- fewer distinct B panels per round, A panels resident across
+    // rounds -- cut the L2 fetch traffic of the fused q|k|v projection but ran 4 % slower: the round-robin order has
+    // more tiles reading the same lines at the same time.)
     const int tiles_mn = tiles_m * tiles_n, total = tiles_mn * nz;
     const int G = gridDim.x, bx = blockIdx.x;
     int first, stride, end;
+    int rn = 0, ngrp = 1, id0 = 0, idm = 0;  // blocked walk (rn > 0): id(j) = id0 + (j / ngrp) * idm + (j % ngrp) * rn
     if ((G & 7) == 0) {
         const int run = (total + 7) >> 3;
         first = (bx & 7) * run + (bx >> 3);
         stride = G >> 3;
         end = (bx & 7) * run + run;
         end = end < total ? end : total;
+        // rounds of RM x RN tiles (RN = up to 8 tile columns, RM = C / RN tile rows), all column groups of a row
+        // group before the next row group
+        const int C = G >> 3, RN = tiles_n < 8 ? tiles_n : 8;
+        if (nz == 1 && (total & 7) == 0 && run % tiles_n == 0 && C % RN == 0 && tiles_n % RN == 0 &&
+            (run / tiles_n) % (C / RN) == 0) {
+            rn = RN;
+            ngrp = tiles_n / RN;
+            id0 = ((bx & 7) * (run / tiles_n) + (bx >> 3) / RN) * tiles_n + (bx >> 3) % RN;
+            idm = (C / RN) * tiles_n;
+        }
     } else {
         first = bx;
         stride = G;
@@ -135,6 +157,25 @@ __global__ __launch_bounds__(512) void gemm_nt_stream(const GemmParams p, int ti
     }
     if (first >= end) return;
     const int ntl = (end - first + stride - 1) / stride;
+    // The list is decoded ONCE into an LDS table (every division below costs a wave ~150 cycles of scalar latency,
+    // and the steps that look a tile up sit on the critical path of all eight waves).
+    auto tile_id = [&](int j) {  // id of this workgroup's j-th tile
+        if (rn > 0) {
+            const int mg = j / ngrp;
+            return id0 + mg * idm + (j - mg * ngrp) * rn;
+        }
+        return first + j * stride;
+    };
+
+    STile *table = (STile *)(smem + S_TAB);
+    for (int j = tid; j < ntl; j += 512) table[j] = stile(p, tile_id(j), tiles_mn, tiles_n);
+    __syncthreads();
+    // field readers (j < ntl <= S_TAB_N: launcher); wave-uniform addresses, i.e. broadcast reads, moved to SGPRs
+    const int *tab32 = (const int *)table;
+    const int64_t *tab64 = (const int64_t *)table;
+    auto tile_m0 = [&](int j) { return __builtin_amdgcn_readfirstlane(tab32[j * 8 + 6]); };
+    auto tile_n0 = [&](int j) { return __builtin_amdgcn_readfirstlane(tab32[j * 8 + 7]); };
+    auto tile_off = [&](int j, int which) { return uniform64(tab64[j * 4 + which]); };  // 0: A, 1: B, 2: C
 
     const int nk1 = (p.K + S_BK - 1) / S_BK;
     const int nk = p.npass * nk1;  // >= 16 (launcher)
@@ -148,18 +189,18 @@ __global__ __launch_bounds__(512) void gemm_nt_stream(const GemmParams p, int ti
     const T *dA = nullptr, *dB = nullptr;             // (batch, head) slice of the DMA tile (uniform)
     uint32_t voa[4], vob[2];                          // per-lane byte offsets of this lane's rows + chunk (< 2^32)
     auto dma_tile = [&](int j) {
-        const STile t = stile(p, first + j * stride, tiles_mn, tiles_n);
-        dA = (const T *)p.A + t.a_off;
-        dB = (const T *)p.B + t.b_off;
+        dA = (const T *)p.A + tile_off(j, 0);
+        dB = (const T *)p.B + tile_off(j, 1);
+        const int tm0 = tile_m0(j), tn0 = tile_n0(j);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            int gm = t.m0 + (wave * 4 + i) * 8 + lrow;
+            int gm = tm0 + (wave * 4 + i) * 8 + lrow;
             gm = gm < p.M ? gm : p.M - 1;
             voa[i] = ((uint32_t)gm * (uint32_t)p.lda + (uint32_t)((i & 1) ? co : ce)) * 2u;
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            int gn = t.n0 + (wave * 2 + i) * 8 + lrow;
+            int gn = tn0 + (wave * 2 + i) * 8 + lrow;
             gn = gn < p.N ? gn : p.N - 1;
             vob[i] = ((uint32_t)gn * (uint32_t)p.ldb + (uint32_t)((i & 1) ? co : ce)) * 2u;
         }
@@ -215,29 +256,32 @@ __global__ __launch_bounds__(512) void gemm_nt_stream(const GemmParams p, int ti
     const int lm = wm * 64 + frow, ln = team * 64 + fq * 4;
     int o_m = 0, o_n = 0;
     int64_t o_off = 0;
-    auto out_tile = [&](const STile &t) {
-        o_m = t.m0 + lm;
-        o_n = t.n0 + ln;
-        o_off = t.c_off + (int64_t)o_m * p.ldc + o_n;
+    auto out_tile = [&](int j) {
+        o_m = tile_m0(j) + lm;
+        o_n = tile_n0(j) + ln;
+        o_off = tile_off(j, 2) + (int64_t)o_m * p.ldc + o_n;
     };
     // The bias is not an epilogue operand either: bias/alpha is added to the accumulators of a tile in the load
     // phases of its steps 1..8 (two units per step), so a leaving unit needs alpha, the activation and the
-    // conversion only.  The bias row of tile j+2 is parked in the stash (parity of j) by one DMA at step 13 of
+    // conversion only.  The bias row of tile j+2 is parked in the stash (slot (j+2) % 3) by one DMA at step 13 of
     // tile j.
     const float inv_alpha = 1.0f / p.alpha;  // (alpha != 0: launcher)
-    auto tile_at = [&](int j) {              // j-th tile of this workgroup's list, clamped to the last one
-        j = j < ntl ? j : ntl - 1;
-        return stile(p, first + j * stride, tiles_mn, tiles_n);
-    };
-    auto bias_dma = [&](int j, int par) {  // one DMA: this wave's 64 bias values of tile j (zeros if no bias)
-        const int n0 = tile_at(j).n0;
+    auto clamp_j = [&](int j) { return j < ntl ? j : ntl - 1; };  // (a tile past the list: the last one again)
+    auto bias_dma = [&](int j, int slot) {  // one DMA: this wave's 64 bias values of tile j (zeros if no bias)
+        const int n0 = tile_n0(clamp_j(j));
+        // the lane id is recomputed here from an opaque zero, so that nothing lane-dependent has to be kept in a
+        // register between two tiles for this once-per-tile DMA (the residual variant has no register to spare)
+        int zero = 0;
+        asm volatile("" : "+v"(zero));
+        const int lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, zero));
         if (lane < 16) {
             const int n = n0 + team * 64 + lane * 4;
             const float *src = (p.bias_mode == 1 && n < p.N) ? p.bias + n : (const float *)g_zero_s;
-            lds_dma16(src, bstash + par * 64);
+            lds_dma16(src, bstash + slot * 64);
         }
     };
-    auto bias_of = [&](int par, int ni) { return *(const f32x4 *)(bstash + par * 64 + ni * 16 + fq * 4); };
+    auto bias_of = [&](int slot, int ni) { return *(const f32x4 *)(bstash + slot * 64 + ni * 16 + fq * 4); };
+    int bslot = 0;  // stash slot of the CURRENT tile's bias row (j % 3); tile j+2's row goes to (bslot + 2) % 3
     char *const sink = (char *)g_sink_s + lane * 16;
     auto store_unit = [&](f32x4 v, int mi, int ni, bool live) {
         const int m = o_m + mi * 16, n = o_n + ni * 16;
@@ -265,10 +309,11 @@ __global__ __launch_bounds__(512) void gemm_nt_stream(const GemmParams p, int ti
             }
         }
     };
-    auto r_load = [&](f32x4 &dst, int mi, int ni, const STile &t) {  // accumulator <- residual (clamped: always valid)
-        int m = t.m0 + lm + mi * 16;
+    int nx_m0 = tile_m0(0), nx_n0 = tile_n0(0);  // origin of the tile whose residual is being loaded (the next one)
+    auto r_load = [&](f32x4 &dst, int mi, int ni) {  // accumulator <- residual of the next tile (clamped: always valid)
+        int m = nx_m0 + lm + mi * 16;
         m = m < p.M ? m : p.M - 1;
-        int n = t.n0 + ln + ni * 16;
+        int n = nx_n0 + ln + ni * 16;
         n = n < p.N ? n : 0;
         const float *rrow = p.R + (int64_t)m * p.ldr;  // (r_rows == 0: launcher)
         const float *src = rrow + n;
@@ -276,7 +321,6 @@ __global__ __launch_bounds__(512) void gemm_nt_stream(const GemmParams p, int ti
     };
 
     f32x4 acc[2][4][4];
-    STile t_cur = stile(p, first, tiles_mn, tiles_n), t_next = t_cur;  // t_next: residual source of the next tile
     int cslot = 0;
     int s_prev = 0;  // stores this wave issued in its previous MFMA phase (they sit between two stages' DMA)
 
@@ -288,7 +332,7 @@ __global__ __launch_bounds__(512) void gemm_nt_stream(const GemmParams p, int ti
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) r_load(acc[0][mi][ni], mi, ni, t_cur);
+            for (int ni = 0; ni < 4; ++ni) r_load(acc[0][mi][ni], mi, ni);
     }
     dma_tile(0);
     issue(std::false_type{});
@@ -309,15 +353,18 @@ __global__ __launch_bounds__(512) void gemm_nt_stream(const GemmParams p, int ti
     // later steps of a long K, which carry no epilogue work.
     auto step = [&](auto PC, auto KC, bool has_prev, int j) {
         constexpr int P = decltype(PC)::value, Q = P ^ 1, KT = decltype(KC)::value;
-        // Units of the previous tile leaving in this step: one per step (0..15); with a residual two in step 0 and
-        // one in steps 1..14 (units 2..15), each followed by the load of the NEXT tile's residual into the registers
-        // it vacated -- so every residual load is at least one full step old at the end of step 15.
-        constexpr int ND = HAS_R ? (KT == 0 ? 2 : (KT <= 14 ? 1 : 0)) : (KT < 16 ? 1 : 0);
-        constexpr int D0 = HAS_R ? (KT == 0 ? 0 : KT + 1) : KT;
+        // Units of the previous tile leaving in this step: one per step (0..15); with a residual one in steps 0..13
+        // and two in step 14 (where most of that register set is already free), each followed by the load of the
+        // NEXT tile's residual into the registers it vacated -- so every residual load is at least one full step
+        // old at the end of step 15.
+        constexpr int ND = HAS_R ? (KT <= 13 ? 1 : (KT == 14 ? 2 : 0)) : (KT < 16 ? 1 : 0);
+        constexpr int D0 = KT;
         constexpr int NR = HAS_R ? ND : 0;
-        constexpr int NR_PREV = !HAS_R ? 0 : (KT == 1 ? 2 : ((KT >= 2 && KT <= 14) ? 1 : 0));  // (KT == 15: strict)
-        constexpr bool BA = KT >= 1 && KT <= 8;                           // bias joins units B0, B0+1 of THIS tile
-        constexpr int B0 = 2 * (KT - 1);
+        constexpr int NR_PREV = (HAS_R && KT >= 1 && KT <= 14) ? 1 : 0;
+        // bias joins THIS tile: two units per step in steps 1..8; with a residual (tightest on registers) one
+        // unit per step in steps 0..15
+        constexpr bool BA = HAS_R ? KT < 16 : (KT >= 1 && KT <= 8);
+        constexpr int B0 = HAS_R ? KT : 2 * (KT - 1);
         constexpr int E_NOW = (KT == 13 ? 1 : 0) + NR;                    // loads issued after this step's stage
         constexpr int E_PREV = (KT == 14 ? 1 : 0) + NR_PREV;
         constexpr int E_BIAS = (KT == 13 ? 1 : 0);                        // ... of them before the load-phase wait
@@ -334,12 +381,15 @@ __global__ __launch_bounds__(512) void gemm_nt_stream(const GemmParams p, int ti
         const bool iss = dj < ntl;
 #endif
         if (iss) issue(std::integral_constant<bool, (KT >= 13)>{});
-        if constexpr (KT == 13) bias_dma(j + 2, P);
+        if constexpr (KT == 13) bias_dma(j + 2, bslot == 0 ? 2 : bslot - 1);  // (j + 2) % 3
         PIO_SSTAMP(1);
         PIO_SSTAMP(2);
         // loads AND stores issued after the stage needed next (stage g+1, issued one load phase ago): the previous
         // MFMA phase's stores and residual loads, this phase's stage and bias row
-        const int allow1 = E_PREV + s_prev + (iss ? 6 : 0) + E_BIAS;
+        // (step 15 with a residual is STRICT: the residual loads of step 14 -- and with them everything older --
+        //  must have landed before the next tile multiplies into those registers)
+        constexpr bool STRICT = HAS_R && KT == 15;
+        const int allow1 = (STRICT ? 0 : E_PREV + s_prev) + (iss ? 6 : 0) + E_BIAS;
         if (team == 1) wait_vm_n(allow1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         PIO_SSTAMP(3);
@@ -353,8 +403,8 @@ __global__ __launch_bounds__(512) void gemm_nt_stream(const GemmParams p, int ti
         if (!(smode & 1)) {
 #endif
         if constexpr (BA) {
-            acc[P][B0 >> 2][B0 & 3] += bias_of(P, B0 & 3) * inv_alpha;
-            acc[P][(B0 + 1) >> 2][(B0 + 1) & 3] += bias_of(P, (B0 + 1) & 3) * inv_alpha;
+            acc[P][B0 >> 2][B0 & 3] += bias_of(bslot, B0 & 3) * inv_alpha;
+            if constexpr (!HAS_R) acc[P][(B0 + 1) >> 2][(B0 + 1) & 3] += bias_of(bslot, (B0 + 1) & 3) * inv_alpha;
         }
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi)
@@ -364,7 +414,7 @@ __global__ __launch_bounds__(512) void gemm_nt_stream(const GemmParams p, int ti
 #pragma unroll
         for (int d = 0; d < ND; ++d) {  // (no branch on has_prev: the first tile's "predecessor" goes to the sink)
             store_unit(acc[Q][(D0 + d) >> 2][(D0 + d) & 3], (D0 + d) >> 2, (D0 + d) & 3, has_prev);
-            if constexpr (HAS_R) r_load(acc[Q][(D0 + d) >> 2][(D0 + d) & 3], (D0 + d) >> 2, (D0 + d) & 3, t_next);
+            if constexpr (HAS_R) r_load(acc[Q][(D0 + d) >> 2][(D0 + d) & 3], (D0 + d) >> 2, (D0 + d) & 3);
             else acc[Q][(D0 + d) >> 2][(D0 + d) & 3] = zero4;
         }
 #pragma unroll
@@ -389,11 +439,15 @@ __global__ __launch_bounds__(512) void gemm_nt_stream(const GemmParams p, int ti
         const bool has_prev = j > 0;
         // (without a next tile the residual loads still run, from the last tile's addresses into the idle
         //  registers: the number of loads per step stays fixed, which is what the counted waits assume)
-        if constexpr (HAS_R) t_next = tile_at(j + 1);
+        if constexpr (HAS_R) {
+            nx_m0 = tile_m0(clamp_j(j + 1));
+            nx_n0 = tile_n0(clamp_j(j + 1));
+        }
         static_for<0, 16>([&](auto kc) { step(PC, kc, has_prev, j); });
 #pragma unroll 1
         for (int kt = 16; kt < nk; ++kt) step(PC, std::integral_constant<int, 16>{}, false, j);
-        out_tile(tile_at(j));  // this tile's result leaves during the next tile (or in the tail)
+        out_tile(j);  // this tile's result leaves during the next tile (or in the tail)
+        bslot = bslot == 2 ? 0 : bslot + 1;
     };
 
     for (int j = 0; j < ntl; j += 2) {
@@ -420,6 +474,17 @@ extern "C" int pio_debug_stream_stamps(unsigned long long *out16) {
 }
 #endif
 
+static int stream_grid(int64_t total) {  // one workgroup per CU, a multiple of 8 (the XCD count) when possible
+    static const int n_cu = [] {
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        return n > 0 ? n : 256;
+    }();
+    int G = (int)(total < n_cu ? total : n_cu);
+    if (G >= 8) G &= ~7;
+    return G;
+}
+
 bool gemm_stream_ok(const GemmParams &p, int batch) {
     const int nk = p.npass * ((p.K + S_BK - 1) / S_BK);
     if (nk < 16 || (p.K % S_BK)) return false;
@@ -432,20 +497,16 @@ bool gemm_stream_ok(const GemmParams &p, int batch) {
     if (p.out_f32 && p.C_lo) return false;
     // per-lane DMA offsets are 32-bit byte offsets inside one (batch, head) slice
     if (((int64_t)p.M * p.lda + p.K) * 2 >= (1ll << 32) || ((int64_t)p.N * p.ldb + p.K) * 2 >= (1ll << 32)) return false;
-    (void)batch;
+    // the per-workgroup tile list is decoded into an LDS table of S_TAB_N entries
+    const int64_t tiles = (int64_t)((p.M + S_BM - 1) / S_BM) * ((p.n_store + S_BN - 1) / S_BN) * batch;
+    const int G = stream_grid(tiles);
+    if ((tiles + G - 1) / G + 8 > S_TAB_N) return false;
     return true;
 }
 
 void gemm_stream_launch(const GemmParams &p, int dtype, int batch, hipStream_t s) {
-    static const int n_cu = [] {
-        int dev = 0, n = 256;
-        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-        return n > 0 ? n : 256;
-    }();
     const int tiles_m = (p.M + S_BM - 1) / S_BM, tiles_n = (p.n_store + S_BN - 1) / S_BN;
-    const int64_t total = (int64_t)tiles_m * tiles_n * batch;
-    int G = (int)(total < n_cu ? total : n_cu);
-    if (G >= 8) G &= ~7;
+    const int G = stream_grid((int64_t)tiles_m * tiles_n * batch);
     dim3 grid((unsigned)G, 1, 1), block(512, 1, 1);
 #define PIO_GK(DTV, R, ACT, OUT) hipLaunchKernelGGL((gemm_nt_stream<DTV, R, ACT, OUT>), grid, block, 0, s, p, tiles_m, tiles_n, batch)
 #define PIO_GS(DTV)                                                      \

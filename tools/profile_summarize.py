@@ -15,7 +15,13 @@ def short(name):
 
 
 res = {"tag": tag}
-stats = glob.glob(f"{out}/trace/*/*kernel_stats.csv")
+def newest(pattern):
+    """gpurun merges every call's output into the same directory: take the most recent file."""
+    files = sorted(glob.glob(pattern), key=os.path.getmtime)
+    return files[-1:]
+
+
+stats = newest(f"{out}/trace/*/*kernel_stats.csv")
 rows = []
 if stats:
     for r in csv.DictReader(open(stats[0])):
@@ -23,7 +29,7 @@ if stats:
                      "avg_us": float(r["AverageNs"]) / 1e3, "pct": float(r["Percentage"])})
 res["kernel_stats"] = rows[:12]
 for key, cname in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
-    f = glob.glob(f"{out}/pmc_{key}/*/*counter_collection.csv")
+    f = newest(f"{out}/pmc_{key}/*/*counter_collection.csv")
     agg = collections.defaultdict(lambda: [0.0, 0])
     if f:
         for r in csv.DictReader(open(f[0])):
@@ -40,6 +46,17 @@ for k in res.get("fetch", {}):
     fk = res["fetch"][k]["kb_per_launch"]
     wk = res.get("write", {}).get(k, {}).get("kb_per_launch", 0.0)
     traffic[k] = {"bytes_per_launch": (2.0 * fk + wk) * 1024.0, "fetch_kb_raw": fk, "write_kb": wk}
+# per kernel FAMILY (template instantiations merged, weighted by launches): what bench.py looks up by kernel name
+fam = collections.defaultdict(lambda: [0.0, 0])
+for k, t in traffic.items():
+    n = res["fetch"][k]["launches"]
+    f = fam[k.split("<")[0]]
+    f[0] += t["bytes_per_launch"] * n
+    f[1] += n
+for k, (tot, n) in fam.items():
+    if k not in traffic:
+        traffic[k] = {"bytes_per_launch": tot / max(n, 1), "launches": n, "family_of": sorted(
+            x for x in traffic if x.startswith(k + "<"))}
 res["traffic"] = traffic
 try:
     res["bench"] = json.loads(open(f"{out}/bench.json").read().strip().splitlines()[-1])
