@@ -130,6 +130,9 @@ __global__ __launch_bounds__(512) void gemm_nt_stream(const GemmParams p, int ti
     // (Walking a run in rounds of 4 x 8 tiles instead -- fewer distinct B panels per round, A panels resident across
     // rounds -- cut the L2 fetch traffic of the fused q|k|v projection but ran 4 % slower: the round-robin order has
     // more tiles reading the same lines at the same time.)
+#ifdef PIO_GEMM_STAMPS
+    const int smode = __builtin_amdgcn_readfirstlane(g_smode);  // (read once: a load per step would distort the phases)
+#endif
     const int tiles_mn = tiles_m * tiles_n, total = tiles_mn * nz;
     const int G = gridDim.x, bx = blockIdx.x;
     int first, stride, end;
@@ -373,13 +376,13 @@ __global__ __launch_bounds__(512) void gemm_nt_stream(const GemmParams p, int ti
         // reads and DMA only -- everything else rides in this wave's own MFMA phase)
         PIO_SSTAMP(0);
 #ifdef PIO_GEMM_STAMPS
-        const int smode = g_smode;
-        if (!(smode & 1)) load_frags(cslot);
         const bool iss = dj < ntl && !(smode & 2);
+        const bool rd = !(smode & 1);
 #else
-        load_frags(cslot);
         const bool iss = dj < ntl;
+        const bool rd = true;
 #endif
+        if (rd) load_frags(cslot);
         if (iss) issue(std::integral_constant<bool, (KT >= 13)>{});
         if constexpr (KT == 13) bias_dma(j + 2, bslot == 0 ? 2 : bslot - 1);  // (j + 2) % 3
         PIO_SSTAMP(1);

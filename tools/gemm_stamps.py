@@ -65,8 +65,8 @@ def run(M, N, K, out_f32, resid, act, mode, iters=20):
     t = [int(v) for v in s]
     d = lambda a, b: t[b] - t[a]
     tail = "" if mode == 3 else f" epilogue(issue) {d(2, 3)} stores-landed +{d(3, 4)}"
-    print(f"M={M} N={N} K={K} f32={int(out_f32)} R={int(resid)} act={act} [{NAMES[mode]}]: {us:7.1f} us | "
-          f"prologue {d(0, 1)} mainloop {d(1, 2)}{tail}", flush=True)
+    print(f"M={M} N={N} K={K} f32={int(out_f32)} R={int(resid)} act={act} [{NAMES[mode]}]: {us:7.1f} us" +
+          (f" | prologue {d(0, 1)} mainloop {d(1, 2)}{tail}" if t[2] > t[0] > 0 else ""), flush=True)
 
 
 def run_stream(M, N, K, out_f32, resid, act, iters=10, smode=0):
@@ -85,13 +85,13 @@ def run_stream(M, N, K, out_f32, resid, act, iters=10, smode=0):
         lib.pio_gemm_kernel_override(prev)
     s = (C.c_ulonglong * 16)()
     assert sdbg(s) == 0
-    names = ["epilogue units", "frag reads + DMA issue", "wait lgkm(+vm)", "barrier", "32 MFMA issued", "wait vm",
-             "barrier"]
+    names = ["LDS fragment reads + DMA issue", "-", "waits (lgkm, team 1: vm)", "barrier",
+             "32 MFMA + epilogue / residual fillers", "wait vm (team 0)", "barrier"]
     for row, what in ((0, "step 9 (with epilogue work)"), (1, "late step (K > 1024)")):
         t = [int(v) for v in s[row * 8:row * 8 + 8]]
         if t[7] <= t[0] or t[7] - t[0] > 100000:
             continue
-        print(f"   stream {what}: " + ", ".join(f"{n} {t[i + 1] - t[i]}" for i, n in enumerate(names)) +
+        print(f"   stream {what}: " + ", ".join(f"{n} {t[i + 1] - t[i]}" for i, n in enumerate(names) if n != "-") +
               f" | total {t[7] - t[0]}", flush=True)
 
 
