@@ -7,8 +7,7 @@
 // of tile j leaves the registers WHILE tile j+1 is being multiplied:
 //   * 8 waves = 4 (M) x 2 (N), 64x64 per wave; TWO accumulator sets (2 x 64 VGPRs): MFMAs of tile j+1 go to one
 //     set while the other set (tile j) is written out, one or two 16x16 units per K step;
-//   * the two waves of a SIMD (wave w and w+4, "teams" 0/1) ping-pong as in the 256x256 kernel: between two
-//     barriers one team owns the matrix pipe, the other does its LDS fragment reads, the DMA refill AND its share
+//   * the two waves of a SIMD (wave w and w+4, "teams" 0/1) ping-pong: while one team owns the matrix pipe, the other does its LDS fragment reads, the DMA refill AND its share
 //     of the previous tile's epilogue (VALU + global stores), then they swap;
 //   * K advances in 64-deep steps through a 3-slot LDS ring (3 x 48 KiB) filled by LDS-DMA two steps ahead; the
 //     step sequence is flattened over the tile list, so the ring never drains between tiles (no per-tile prologue);
@@ -349,7 +348,10 @@ __global__ __launch_bounds__(512) void gemm_nt_stream(const GemmParams p, int ti
             acc[1][mi][ni] = zero4;
         }
     __builtin_amdgcn_s_barrier();
-    if (team == 1) __builtin_amdgcn_s_barrier();  // team 1 runs half a step behind
+    // (GELU variant: its MFMA phase, ~1000 cycles with the activation among the MFMAs, is the longer one; there the
+    //  classic two meeting points per step -- team 1 half a step behind -- measured 5 % faster than one)
+    constexpr bool ONE_BARRIER = ACT == 0;
+    if (!ONE_BARRIER && team == 1) __builtin_amdgcn_s_barrier();
 
     // One K step.  KT (compile time) = position inside the tile for the first 16 steps -- it fixes which
     // accumulator registers leave / are loaded in this step, so every register index is static -- and 16 for the
@@ -396,7 +398,13 @@ __global__ __launch_bounds__(512) void gemm_nt_stream(const GemmParams p, int ti
         if (team == 1) wait_vm_n(allow1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         PIO_SSTAMP(3);
-        __builtin_amdgcn_s_barrier();
+        // ONE barrier per step and wave: team 1 meets team 0 here, after its load phase, team 0 after its MFMA phase
+        // (below).  Both teams run the same instruction stream LOAD(0) MFMA(0) LOAD(1) MFMA(1) ...; cutting it at
+        // different points puts them half a step apart: between two barriers team 0 runs LOAD(g) MFMA(g) while team
+        // 1 runs MFMA(g-1) LOAD(g) -- one team's MFMAs beside the other's loads without a second meeting point.
+        // Stage g+1 is complete before the barrier (both teams waited for their pieces), and the slot refilled in
+        // LOAD(g) held stage g-1, whose last reads (team 1's LOAD(g-1)) finished before the previous barrier.
+        if (!ONE_BARRIER || team == 1) __builtin_amdgcn_s_barrier();
         // ================= MFMA phase: 32 MFMAs; beside them (an MFMA holds the vector issue for 8 of its 16 cycles)
         // the bias of two units of this tile, the unit(s) of the previous tile that leave and, into their registers,
         // the residual of the next tile
@@ -434,7 +442,7 @@ __global__ __launch_bounds__(512) void gemm_nt_stream(const GemmParams p, int ti
         if (team == 0) wait_vm_n(allow1 + S_NOW + (E_NOW - E_BIAS));
         s_prev = S_NOW;
         PIO_SSTAMP(6);
-        __builtin_amdgcn_s_barrier();
+        if (!ONE_BARRIER || team == 0) __builtin_amdgcn_s_barrier();
         PIO_SSTAMP(7);
         cslot = cslot == S_NST - 1 ? 0 : cslot + 1;
     };
@@ -457,7 +465,7 @@ __global__ __launch_bounds__(512) void gemm_nt_stream(const GemmParams p, int ti
         run_tile(std::integral_constant<int, 0>{}, j);
         if (j + 1 < ntl) run_tile(std::integral_constant<int, 1>{}, j + 1);
     }
-    if (team == 0) __builtin_amdgcn_s_barrier();  // pairs with team 1's last barrier
+    if (!ONE_BARRIER && team == 0) __builtin_amdgcn_s_barrier();  // pairs with team 1's last barrier
 
     // ---- the last tile's result leaves without cover
     const int lp = (ntl - 1) & 1;
