@@ -57,11 +57,6 @@ constexpr int S_TAB_N = 256;            // tile-table entries (32 B each): this 
 constexpr int S_TAB = S_RING + 8 * S_BIAS_W;
 constexpr int S_SMEM = S_TAB + S_TAB_N * 32;
 
-template <int N>
-__device__ __forceinline__ void wait_vm_c() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
 __device__ __forceinline__ void wait_vm_n(int n) {  // n: wave-uniform
 #define PIO_W(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
     switch (n) {
