@@ -37,7 +37,8 @@ static __device__ __attribute__((aligned(16))) uint32_t g_sink_s[64 * 4];
 // Dev-only (tools/gemm_stamps.py): wave 0 of workgroup 0 records s_memtime inside one unrolled step with epilogue
 // work (row 0: KT == 9 of a tile that has a predecessor) and inside the late steps of a long K (row 1).
 __device__ unsigned long long g_sstamps[2][8];
-__device__ int g_smode;  // ablations: bit 0 = no fragment reads / MFMAs, bit 1 = no DMA after the prologue
+__device__ int g_smode;  // ablations: bit 0 = no fragment reads / MFMAs, bit 1 = no DMA after the prologue,
+                         // bit 2 = residual loads from one small (cache-resident) region
 #define PIO_SSTAMP(i)                                                                                         \
     do {                                                                                                      \
         if ((KT == 9 ? has_prev : KT == 16) && blockIdx.x == 0 && threadIdx.x == 0)                           \
@@ -313,7 +314,14 @@ __global__ __launch_bounds__(512) void gemm_nt_stream(const GemmParams p, int ti
         int n = nx_n0 + ln + ni * 16;
         n = n < p.N ? n : 0;
         const float *rrow = p.R + (int64_t)m * p.ldr;  // (r_rows == 0: launcher)
+#ifdef PIO_GEMM_STAMPS
+        const float *src = (smode & 4) ? p.R + (lm & 63) * p.ldr + (n & 127) : rrow + n;  // ablation: cache-resident residual
+#else
         const float *src = rrow + n;
+#endif
+#ifdef PIO_GEMM_STAMPS
+        if (smode & 8) return;  // ablation: no residual loads at all (wrong results, the loads are not counted either)
+#endif
         asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(src) : "memory");
     };
 
@@ -420,14 +428,21 @@ __global__ __launch_bounds__(512) void gemm_nt_stream(const GemmParams p, int ti
 #pragma unroll
         for (int d = 0; d < ND; ++d) {  // (no branch on has_prev: the first tile's "predecessor" goes to the sink)
             store_unit(acc[Q][(D0 + d) >> 2][(D0 + d) & 3], (D0 + d) >> 2, (D0 + d) & 3, has_prev);
-            if constexpr (HAS_R) r_load(acc[Q][(D0 + d) >> 2][(D0 + d) & 3], (D0 + d) >> 2, (D0 + d) & 3);
-            else acc[Q][(D0 + d) >> 2][(D0 + d) & 3] = zero4;
+            if constexpr (!HAS_R) acc[Q][(D0 + d) >> 2][(D0 + d) & 3] = zero4;
         }
+        // With a residual the epilogue arithmetic stays among the FIRST sixteen MFMAs (letting it spread over all 32
+        // costs the registers this variant does not have), and the residual loads come LAST: inline asm is a
+        // scheduling boundary, in the middle of the phase it kept the arithmetic out from among the MFMAs altogether.
+        if constexpr (HAS_R) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni)
                 acc[P][mi][ni] = Op<DT>::mfma16(bf[ni][1], af[mi][1], acc[P][mi][ni]);
+        if constexpr (HAS_R) {
+#pragma unroll
+            for (int d = 0; d < ND; ++d) r_load(acc[Q][(D0 + d) >> 2][(D0 + d) & 3], (D0 + d) >> 2, (D0 + d) & 3);
+        }
 #ifdef PIO_GEMM_STAMPS
         }
 #endif
