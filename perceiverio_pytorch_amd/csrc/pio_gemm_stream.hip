@@ -38,7 +38,8 @@ static __device__ __attribute__((aligned(16))) uint32_t g_sink_s[64 * 4];
 // work (row 0: KT == 9 of a tile that has a predecessor) and inside the late steps of a long K (row 1).
 __device__ unsigned long long g_sstamps[2][8];
 __device__ int g_smode;  // ablations: bit 0 = no fragment reads / MFMAs, bit 1 = no DMA after the prologue,
-                         // bit 2 = residual loads from one small (cache-resident) region
+                         // bit 2 = residual loads from one small (cache-resident) region, bit 3 = no residual loads,
+                         // bit 4 = no fragment reads but the MFMAs still run
 #define PIO_SSTAMP(i)                                                                                         \
     do {                                                                                                      \
         if ((KT == 9 ? has_prev : KT == 16) && blockIdx.x == 0 && threadIdx.x == 0)                           \
@@ -382,7 +383,7 @@ __global__ __launch_bounds__(512) void gemm_nt_stream(const GemmParams p, int ti
         PIO_SSTAMP(0);
 #ifdef PIO_GEMM_STAMPS
         const bool iss = dj < ntl && !(smode & 2);
-        const bool rd = !(smode & 1);
+        const bool rd = !(smode & 17);  // bit 4: MFMAs run on whatever the fragment registers hold
 #else
         const bool iss = dj < ntl;
         const bool rd = true;

@@ -77,7 +77,7 @@ def run_stream(M, N, K, out_f32, resid, act, iters=10, smode=0):
     torch.cuda.synchronize()
     assert lib.pio_debug_stream_mode(smode) == 0
     if smode:
-        print(f" -- ablation mode {smode}: " + {1: "DMA only", 2: "LDS reads + MFMA only", 3: "barriers only", 4: "residual from a cache-resident region", 8: "no residual loads"}.get(smode, str(smode)))
+        print(f" -- ablation mode {smode}: " + {1: "DMA only", 2: "LDS reads + MFMA only", 3: "barriers only", 4: "residual from a cache-resident region", 8: "no residual loads", 16: "MFMAs without fragment reads", 18: "MFMAs only (no LDS reads, no DMA)"}.get(smode, str(smode)))
     prev = lib.pio_gemm_kernel_override(1)
     try:
         run(M, N, K, out_f32, resid, act, 0, iters=iters)
@@ -104,6 +104,8 @@ if __name__ == "__main__" and "--stream" in sys.argv:
         run_stream(16384, 1024, 1024, False, False, 0, smode=sm)
         run_stream(16384, 3072, 1024, False, False, 0, smode=sm)
     run_stream(16384, 3072, 1024, False, False, 0, smode=0)
+    run_stream(16384, 1024, 1024, False, False, 0, smode=18)
+    run_stream(16384, 1024, 1024, False, False, 0, smode=16)
     run_stream(16384, 1024, 1024, True, True, 0, smode=4)
     run_stream(16384, 1024, 1024, True, True, 0, smode=8)
     run_stream(16384, 1024, 1024, True, True, 0, smode=0)
