@@ -149,18 +149,16 @@ __global__ __launch_bounds__(512) void gemm_nt_256(const GemmParams p) {
 
     if constexpr ((VAR & 4) != 0) {
         // PING-PONG: the two waves that share a SIMD (wave w and w+4 = the two wave rows wr 0/1) run half a K tile
-        // out of phase: between two barriers one row issues its LDS reads + DMA refill (LOAD) while the other
-        // owns the matrix pipe (MFMA), then they swap.  wr==1 is delayed by one barrier at the start and wr==0
-        // pads one at the end.  Intervals I_0, I_1, ...:  wr0: LOAD(t) in I_2t, MFMA(t) in I_2t+1;
-        // wr1: LOAD(t) in I_2t+1, MFMA(t) in I_2t+2.  Tile t+1 is first read in I_2t+2, so every wave waits for
-        // its own pieces of it right before the barrier that opens I_2t+2 (wr0: end of MFMA(t); wr1: end of
-        // LOAD(t)); the slot of tile t-1 is free after that same barrier (wr1 read it in I_2t-1 and drained
-        // lgkmcnt before leaving), which is where wr0's LOAD(t) refills it with tile t+3.
+        // out of phase: while one row issues its LDS reads + DMA refill (LOAD) the other owns the matrix pipe (MFMA).
+        // Both rows run the same instruction stream LOAD(0) MFMA(0) LOAD(1) MFMA(1) ... with ONE barrier per K tile
+        // and wave, at different points: wr1 meets wr0 after its LOAD, wr0 after its MFMA phase -- so between two
+        // barriers wr0 runs LOAD(t) MFMA(t) while wr1 runs MFMA(t-1) LOAD(t).  Tile t+1 is complete before barrier t
+        // (wr0 waits for its pieces at the end of MFMA(t), wr1 at the end of LOAD(t)); the slot refilled in LOAD(t)
+        // (tile t+3) held tile t-1, whose last reads (wr1's LOAD(t-1)) drained before barrier t-1.
         V8 af[8], bf[4];
         wait_vm_tiles<0>(nk - 1 < AHEAD - 1 ? nk - 1 : AHEAD - 1);
         __builtin_amdgcn_s_barrier();  // tile 0 visible to everyone
         PIO_STAMP(1);
-        if (wr == 1) __builtin_amdgcn_s_barrier();
         for (int kt = 0; kt < nk; ++kt) {
             const int rem = nk - 2 - kt;
             const int infl = rem < 0 ? 0 : (rem > 2 ? 2 : rem);
@@ -168,17 +166,18 @@ __global__ __launch_bounds__(512) void gemm_nt_256(const GemmParams p) {
             if (kt + AHEAD < nk) stage(kt + AHEAD);
             if (wr == 1) wait_vm_tiles<0>(infl);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
+            if (wr == 1) __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int mi = 0; mi < 8; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = Op<DT>::mfma16(bf[ni], af[mi], acc[mi][ni]);
             __builtin_amdgcn_s_setprio(0);
-            if (wr == 0) wait_vm_tiles<0>(infl);
-            __builtin_amdgcn_s_barrier();
+            if (wr == 0) {
+                wait_vm_tiles<0>(infl);
+                __builtin_amdgcn_s_barrier();
+            }
         }
-        if (wr == 0) __builtin_amdgcn_s_barrier();
     } else if constexpr (PREFETCH) {
         // tile kt+1's fragments are read while tile kt is multiplied; the refill goes into tile kt's own slot
         V8 af0[8], bf0[4], af1[8], bf1[4];
