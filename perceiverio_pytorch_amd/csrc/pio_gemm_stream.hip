@@ -6,22 +6,34 @@
 // and the MFMAs idle during the epilogues.  Here one workgroup per CU walks a LIST of 256x128 tiles and the result
 // of tile j leaves the registers WHILE tile j+1 is being multiplied:
 //   * 8 waves = 4 (M) x 2 (N), 64x64 per wave; TWO accumulator sets (2 x 64 VGPRs): MFMAs of tile j+1 go to one
-//     set while the other set (tile j) is written out, one or two 16x16 units per K step;
-//   * the two waves of a SIMD (wave w and w+4, "teams" 0/1) ping-pong: while one team owns the matrix pipe, the other does its LDS fragment reads, the DMA refill AND its share
-//     of the previous tile's epilogue (VALU + global stores), then they swap;
+//     set while the other set (tile j) is written out, one 16x16 unit per K step;
+//   * a wave alternates between a LOAD phase (LDS fragment reads + DMA refill, nothing else: the partner wave's
+//     MFMAs hold the vector issue, a VALU instruction costs ~20 cycles there) and an MFMA phase whose 32 MFMAs carry
+//     the epilogue arithmetic of the previous tile among them (an MFMA holds the issue 8 of its 16 cycles);
+//   * the two waves of a SIMD (wave w and w+4, "teams" 0/1) run the SAME instruction stream LOAD(0) MFMA(0) LOAD(1)
+//     MFMA(1) ... with ONE barrier per step and wave, at different points: team 1 meets team 0 after its LOAD
+//     phase, team 0 after its MFMA phase -- between two barriers team 0 runs LOAD(g) MFMA(g), team 1 MFMA(g-1)
+//     LOAD(g): one team's MFMAs beside the other's loads (the GELU variant keeps two meeting points per step);
 //   * K advances in 64-deep steps through a 3-slot LDS ring (3 x 48 KiB) filled by LDS-DMA two steps ahead; the
 //     step sequence is flattened over the tile list, so the ring never drains between tiles (no per-tile prologue);
 //     the DMA address is a wave-uniform base (tile, K step, pass) plus a per-lane 32-bit offset fixed per tile;
 //   * 128-byte LDS rows, 16-byte chunk c of row r stored at c ^ ((r >> 1) & 7): conflict-free ds_read_b128;
 //   * the first 16 steps of a tile are unrolled, so which accumulator registers leave in which step is static;
-//   * residual GEMMs (out = A*B^T + bias + R): R is not an epilogue read -- the accumulators of tile j+1 are
-//     LOADED with R (global_load straight into the MFMA C registers, issued from the load phases of tile j's
-//     second half), so the R traffic also overlaps the MFMAs and the epilogue is alpha/bias/convert/store only;
-//   * the bias row of a tile is parked in a per-wave LDS stash by one more DMA at the tile's first step;
-//   * every wait on memory is a COUNTED s_waitcnt vmcnt(n): n = the loads this wave issued after the stage it
-//     needs (loads return in order; stores are not counted, which only makes the wait stricter).
-// Results are identical to gemm_nt_256 / gemm_nt_128 (same MFMA, same K order, fp32 epilogue), except that a
-// residual enters the fp32 accumulation first instead of last.
+//   * residual GEMMs (out = A*B^T + bias + R): R is not an epilogue read -- right after a unit of tile j has been
+//     stored, the residual of tile j+1 is LOADED into the registers it vacated (global_load straight into the MFMA C
+//     registers, at the end of that MFMA phase), so the R traffic overlaps the MFMAs as well;
+//   * the bias is not an epilogue operand either: the bias row of tile j+2 is parked in a per-wave LDS stash
+//     (three slots) by one more DMA at step 13 of tile j, and bias/alpha is added to the accumulators of a tile
+//     during its own first steps;
+//   * the tile list of a workgroup is decoded once into an LDS table (tile ids walk an XCD's run of the tile grid in
+//     rounds of (C/8) x 8 tiles, C = workgroups per XCD);
+//   * every wait on memory is a COUNTED s_waitcnt vmcnt(n): n = the vector-memory operations this wave issued after
+//     the stage it needs.  Loads return in order; stores are counted too -- lanes outside the matrix store to a sink
+//     so the number of stores per step is fixed -- and the build fails if a variant spills (scratch traffic would
+//     join the counted stream unseen).
+// Results are identical to gemm_nt_256 / gemm_nt_128 (same MFMA, same K order, fp32 epilogue), except that bias and
+// residual enter the fp32 accumulation early instead of last.
+// Shapes: K % 64 == 0, K*passes >= 1024, N % 4 == 0 (gemm_stream_ok); everything else stays on the tile kernels.
 #include <type_traits>
 
 #include "pio_gemm_common.h"
