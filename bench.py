@@ -198,7 +198,7 @@ def main():
         L.check(lib.pio_prof_begin(4096 * nprof), "pio_prof_begin")
         for _ in range(nprof):
             step()
-        NCLS = 8  # PIO_PROF_CLASSES
+        NCLS = 9  # PIO_PROF_CLASSES
         ms = (C.c_double * NCLS)()
         fl = (C.c_double * NCLS)()
         by = (C.c_double * NCLS)()
@@ -247,7 +247,7 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = world * B * args.steps / elapsed
     names = ["gemm_nt_256", "gemm_nt_128_batched", "layernorm_cast", "softmax", "pack", "flash_attn",
-             "gemm_nt_128_flat", "gemm_nt_stream"]
+             "gemm_nt_128_flat", "gemm_nt_stream", "gemm_nt_wide"]
     kernels = {}
     for i, nm in enumerate(names):
         if ln[i]:
@@ -266,7 +266,8 @@ def main():
             traffic = json.load(f)["pio::" + names[dom]]["bytes_per_launch"]
     except Exception:  # noqa: BLE001  (no committed profile yet)
         traffic = None
-    roofline = {"kernel": f"pio::{names[dom]} (weight GEMMs of the latent stack: fused q|k|v, out, fc1, fc2 projections)",
+    roofline = {"kernel": f"pio::{names[dom]} (weight GEMMs of the latent stack: out, fc1, fc2 projections; the fused "
+                          f"q|k|v projection runs on pio::gemm_nt_wide, see kernels)",
                 "bound": "mfma", "achieved": g["algo_tflops"], "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": g["algo_tflops"] / MFMA_PEAK_TFLOPS, "traffic": traffic,
                 "avg_launch_us": g["avg_us"], "launches_per_step": g["launches_per_step"],

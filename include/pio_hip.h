@@ -121,8 +121,9 @@ const char *pio_error_string(int code);
 
 /* --- per-launch timing for benchmarks (NOT thread-safe, off by default) ------------------------ */
 /* classes: 0 gemm_nt_256, 1 batched gemm_nt_128, 2 layernorm/cast, 3 softmax, 4 pack, 5 fused attention,
- *          6 flat gemm_nt_128, 7 gemm_nt_stream (persistent streaming kernel: the latent stack's weight GEMMs) */
-#define PIO_PROF_CLASSES 8
+ *          6 flat gemm_nt_128, 7 gemm_nt_stream (persistent streaming kernel: the latent stack's weight GEMMs),
+ *          8 gemm_nt_wide (persistent 256x256 four-wave kernel: the fused q|k|v projection) */
+#define PIO_PROF_CLASSES 9
 /* Start recording a HIP-event pair around every kernel launch (up to max_records launches). */
 int pio_prof_begin(int32_t max_records);
 /* Stop, wait for the recorded launches and sum per class: device milliseconds, ALGORITHMIC flops
@@ -132,7 +133,8 @@ int pio_prof_end(double *ms, double *flops, double *bytes, int64_t *launches);
 
 /* --- kernel selection of pio_gemm_nt, for tests and A/B benchmarks ------------------------------- */
 /* 0: automatic (default; env PIO_GEMM_TILE gives the initial value), 128: 128x128 tile, 256: 256x256 tile,
- * 1: persistent 256x128 streaming kernel wherever it is legal.  Returns the previous setting. */
+ * 1: persistent 256x128 streaming kernel wherever it is legal, 2: persistent 256x256 four-wave kernel wherever
+ * it is legal.  Returns the previous setting. */
 int pio_gemm_kernel_override(int which);
 
 /* --- weight packing (one-off, after load_state_dict) ------------------------------------------ */

@@ -300,6 +300,19 @@ int gemm_nt_launch(const pio_gemm_t &g, hipStream_t s) {
                    (int64_t)tm256 * tn256 >= 128;
         if (forced == 128) big = false;
         if (forced == 256) big = true;
+        // Persistent 256x256 four-wave kernel (pio_gemm_wide.hip): plain 16-bit-out projections with two or more
+        // tiles per CU (its epilogue is exposed, but cheap: bias + store).  Override 2 forces it wherever it is legal.
+        {
+            bool wide = g.batch == 1 && g.M >= 2048 && (double)tn256 * 256.0 <= 1.25 * p.n_store &&
+                        (int64_t)tm256 * tn256 >= 512;
+            if (forced == 2) wide = true;
+            if (forced == 1 || forced == 128 || forced == 256) wide = false;
+            if (wide && gemm_wide_ok(p, g.batch)) {
+                ProfScope prof(PROF_GEMM_WIDE, algo_flops, algo_bytes, s);
+                gemm_wide_launch(p, g.dtype, s);
+                return launch_status();
+            }
+        }
         // Persistent 256x128 streaming kernel (epilogue of tile j hidden behind the MFMAs of tile j+1): deep-K flat
         // problems with about two or more tiles per CU (with fewer there is nothing to hide an epilogue behind and
         // the 256x256 tile's lower operand traffic wins).  Override 1 forces it wherever it is legal.

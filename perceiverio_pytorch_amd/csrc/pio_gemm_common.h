@@ -126,4 +126,8 @@ void gemm256_launch(const GemmParams &p, int dtype, bool attn, int tiles_m, int 
 bool gemm_stream_ok(const GemmParams &p, int batch);
 void gemm_stream_launch(const GemmParams &p, int dtype, int batch, hipStream_t s);
 
+// persistent 256x256-tile four-wave kernel (pio_gemm_wide.hip): plain 16-bit-out projections
+bool gemm_wide_ok(const GemmParams &p, int batch);
+void gemm_wide_launch(const GemmParams &p, int dtype, hipStream_t s);
+
 }  // namespace pio

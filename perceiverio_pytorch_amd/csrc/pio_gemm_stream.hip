@@ -49,6 +49,9 @@ static __device__ __attribute__((aligned(16))) uint32_t g_sink_s[64 * 4];
 // Dev-only (tools/gemm_stamps.py): wave 0 of workgroup 0 records s_memtime inside one unrolled step with epilogue
 // work (row 0: KT == 9 of a tile that has a predecessor) and inside the late steps of a long K (row 1).
 __device__ unsigned long long g_sstamps[2][8];
+// ... and, around the whole kernel, s_memtime (shader cycles) and s_memrealtime (100 MHz): their ratio is the clock the
+// chip holds under this kernel's load (MI355X_MICROARCH.md, "DVFS give-back" item 6).
+__device__ unsigned long long g_sclk[4];
 __device__ int g_smode;  // ablations: bit 0 = no fragment reads / MFMAs, bit 1 = no DMA after the prologue,
                          // bit 2 = residual loads from one small (cache-resident) region, bit 3 = no residual loads,
                          // bit 4 = no fragment reads but the MFMAs still run
@@ -140,6 +143,10 @@ __global__ __launch_bounds__(512) void gemm_nt_stream(const GemmParams p, int ti
     // more tiles reading the same lines at the same time.)
 #ifdef PIO_GEMM_STAMPS
     const int smode = __builtin_amdgcn_readfirstlane(g_smode);  // (read once: a load per step would distort the phases)
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        g_sclk[0] = __builtin_amdgcn_s_memtime();
+        g_sclk[1] = __builtin_amdgcn_s_memrealtime();
+    }
 #endif
     const int tiles_mn = tiles_m * tiles_n, total = tiles_mn * nz;
     const int G = gridDim.x, bx = blockIdx.x;
@@ -497,11 +504,20 @@ __global__ __launch_bounds__(512) void gemm_nt_stream(const GemmParams p, int ti
         store_unit(acc[PAR][mi][ni], mi, ni, true);
     if (lp == 0) { PIO_TAIL(0) } else { PIO_TAIL(1) }
 #undef PIO_TAIL
+#ifdef PIO_GEMM_STAMPS
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        g_sclk[2] = __builtin_amdgcn_s_memtime();
+        g_sclk[3] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
 }
 
 #ifdef PIO_GEMM_STAMPS
 extern "C" int pio_debug_stream_mode(int mode) {
     return hipMemcpyToSymbol(HIP_SYMBOL(g_smode), &mode, sizeof(int)) == hipSuccess ? 0 : 1;
+}
+extern "C" int pio_debug_stream_clock(unsigned long long *out4) {
+    return hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_sclk), sizeof(g_sclk)) == hipSuccess ? 0 : 1;
 }
 extern "C" int pio_debug_stream_stamps(unsigned long long *out16) {
     return hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_sstamps), sizeof(g_sstamps)) == hipSuccess ? 0 : 1;

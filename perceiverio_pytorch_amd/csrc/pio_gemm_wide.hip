@@ -1,0 +1,460 @@
+// gemm_nt_wide: C[M,N] = alpha * A[M,K] B[N,K]^T + bias, 16-bit out -- persistent 256x256 tiles, FOUR waves (one per
+// SIMD), each wave a 128x128 quarter with its 256 accumulator registers in AGPRs.
+//
+// Why a third GEMM: the streaming kernel (pio_gemm_stream.hip, 256x128 tiles, eight waves in two teams) spends a
+// step of 1024 MFMA-cycles in ~2000 cycles: each wave alternates a load phase (16 LDS reads + 6 DMA pieces, bound
+// by the CU's 64 B/clk vector-memory path: 48 KiB per step = 768 cycles at full rate) and an MFMA phase, and the two
+// phases of the two teams only overlap pairwise.  Here a wave never leaves its MFMA stream: per phase (one K slice
+// of 32: 64 MFMAs = 1024 cycles) it issues, BETWEEN its MFMAs, the 16 LDS reads of the next slice's fragments into
+// a second fragment register set and 8 DMA pieces of the slice four ahead -- 64 KiB of operands per 2048
+// MFMA-cycles, i.e. half the vector-memory rate and two thirds of the LDS-read bytes of the streaming kernel per
+// FLOP.  One barrier per phase.  The price: with one accumulator set the tile's result leaves in an exposed
+// epilogue (no second set to drip from), so this kernel serves the projections whose epilogue is cheap -- bias and
+// a 16-bit store (the fused q|k|v projection: 29 % of a self-attend layer) -- and the others stay on the streaming
+// kernel.
+//
+// LDS: ring of 4 slices x (A 256 rows x 64 B | B 256 rows x 64 B) = 128 KiB; a row's four 16-B chunks are stored at
+// position chunk ^ f((row >> 2) & 3), f = {0, 2, 3, 1}: conflict-free for ds_read_b128's lane groups
+// ({0-3,12-15,20-27}, {4-11,16-19,28-31}, ...: MI355X_MICROARCH.md, LDS table) both for fragment rows lane & 15 (A)
+// and for the permuted B rows below.  Filled by global_load_lds_dwordx4 pieces of 16 rows x 64 B whose per-lane
+// SOURCE address carries the swizzle (the DMA writes LDS linearly).
+//
+// B rows are permuted inside each 32-column group so that a lane's two units (ni even / odd) hold 8 CONSECUTIVE
+// output columns: MFMA column index c (0..15) of unit ni is column 32 * (ni / 2) + 8 * (c / 4) + 4 * (ni & 1) + c % 4,
+// so a lane (row lane & 15, index group lane >> 4) stores 16 bytes per unit pair instead of two 8-byte pieces.
+//
+// Pipeline, per wave, phase g (K slice g of the flattened slice sequence over this workgroup's tiles):
+//   MFMAs on fragment set g & 1 | LDS reads of slice g+1 into set (g+1) & 1 | DMA of slice g+4 into ring slot g & 3
+//   (slice g left that slot for the registers during phase g-1) | s_waitcnt vmcnt(16): all but this and the
+//   previous phase's pieces have landed, i.e. slice g+2 is complete | lgkmcnt(0) | barrier.
+// Every phase issues exactly 8 pieces (past the end of the work they go to a sink region), and the epilogue always
+// issues its 32 stores (out-of-range ones to a global sink), so the counted waits are exact.
+//
+// Reference semantics: y = x W^T + b of nn.Linear (perceiver_io/transformer_primitives.py:93-95, 110).
+#include <type_traits>
+
+#include "pio_gemm_common.h"
+
+namespace pio {
+
+constexpr int W_BM = 256, W_BN = 256, W_BK = 32, W_NST = 4;
+constexpr int W_AB = W_BM * W_BK * 2;    // 16 KiB of A per slice
+constexpr int W_STAGE = 2 * W_AB;        // 32 KiB
+constexpr int W_RING = W_NST * W_STAGE;  // 128 KiB
+constexpr int W_BIAS = W_RING + 4 * 1024;  // after the per-wave sinks for the pieces past the end: per-wave bias rows
+constexpr int W_SMEM = W_BIAS + 4 * 512;
+
+static __device__ __attribute__((aligned(16))) uint32_t g_sink_w[64 * 4];
+static __device__ __attribute__((aligned(16))) uint32_t g_zero_w[4] = {0, 0, 0, 0};
+
+#ifdef PIO_GEMM_STAMPS
+// Dev-only (tools/gemm_stamps.py --wide): wave 0 of workgroup 0 records s_memtime inside its ordinary phases (the
+// last one executed survives) and, around the kernel, s_memtime / s_memrealtime (the clock held under load).
+__device__ unsigned long long g_wstamps[8];
+__device__ unsigned long long g_wclk[4];
+#ifndef PIO_WIDE_ABL
+#define PIO_WIDE_ABL 0  // timing-only ablations, compile time: bit 0 = no LDS fragment reads, 1 = no DMA pieces, 2 = no barrier
+#endif
+#ifdef PIO_WIDE_PHASE_STAMPS  // (they cost ~76 cycles each and pull the stamped wave out of step with the others)
+#define PIO_WSTAMP(i)                                                            \
+    do {                                                                         \
+        if (!FIRST && P == 0 && blockIdx.x == 0 && threadIdx.x == 0)             \
+            g_wstamps[i] = __builtin_readcyclecounter();                         \
+    } while (0)
+#else
+#define PIO_WSTAMP(i)
+#endif
+#else
+#define PIO_WSTAMP(i)
+#endif
+
+template <int I, int N, class F>
+__device__ __forceinline__ void wide_for(F &&f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        wide_for<I + 1, N>(f);
+    }
+}
+
+__device__ __forceinline__ void wide_dma16(const void *src, void *lds) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                     (__attribute__((address_space(3))) void *)lds, 16, 0, 0);
+}
+
+// Reads one accumulator element where it lives (an AGPR): without this the register allocator moves all 256 to VGPRs
+// at the end of the K loop and a handful of address registers spill.
+__device__ __forceinline__ float acc_read(float a) {
+    float v;
+    asm("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(a));
+    return v;
+}
+
+// The MFMA as inline assembly with its accumulator pinned to AGPRs ("+a"), accumulating in place: left to the
+// register allocator, the 256 accumulator registers wander between the two files and a few of them spill.  (The
+// compiler's hazard recognizer does not look inside: the only dependent reader of an accumulator within fewer than
+// 64 MFMAs is the epilogue, which starts behind the last phase's waits and barrier.)
+template <int DT>
+__device__ __forceinline__ void mfma_acc(f32x4 &c, typename Op<DT>::V8 a, typename Op<DT>::V8 b) {
+    if constexpr (DT == PIO_DT_F16) asm("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+    else asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+template <int DT>
+__device__ __forceinline__ void mfma_first(f32x4 &c, typename Op<DT>::V8 a, typename Op<DT>::V8 b) {
+    if constexpr (DT == PIO_DT_F16) asm("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=a"(c) : "v"(a), "v"(b));
+    else asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(c) : "v"(a), "v"(b));
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void gemm_nt_wide(const GemmParams p, int tiles_m, int tiles_n) {
+    typedef typename Op<DT>::T T;
+    typedef typename Op<DT>::V8 V8;
+    __shared__ __attribute__((aligned(16))) char smem[W_SMEM];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+#ifdef PIO_GEMM_STAMPS
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        g_wclk[0] = __builtin_amdgcn_s_memtime();
+        g_wclk[1] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
+
+    // ---- this workgroup's tiles.  Blocked walk: XCD x (= blockIdx & 7, its own L2) owns tile rows
+    // [x * RM, (x + 1) * RM); its C workgroups cover RM rows x CW columns per round, so the tiles in flight in one L2
+    // share RM A panels and CW B panels.  Otherwise: a contiguous run of row-major tile ids per XCD, round-robin.
+    const int total = tiles_m * tiles_n, G = gridDim.x, bx = blockIdx.x;
+    int ntl, first = 0, stride = 1, b_tm = 0, b_tn = 0, b_cw = 0;
+    {
+        const int x = bx & 7, c = bx >> 3, C = G >> 3;
+        const int RM = tiles_m >> 3;
+        if ((G & 7) == 0 && (tiles_m & 7) == 0 && RM <= C && C % RM == 0 && tiles_n % (C / RM) == 0) {
+            b_cw = C / RM;
+            b_tm = x * RM + c % RM;
+            b_tn = c / RM;
+            ntl = tiles_n / b_cw;
+        } else if ((G & 7) == 0) {
+            const int run = (total + 7) >> 3;
+            first = x * run + c;
+            stride = C;
+            int end = x * run + run;
+            end = end < total ? end : total;
+            ntl = first < end ? (end - first + stride - 1) / stride : 0;
+        } else {
+            first = bx;
+            stride = G;
+            ntl = first < total ? (total - first + stride - 1) / stride : 0;
+        }
+    }
+    if (ntl <= 0) return;
+    auto tile_mn = [&](int j, int &tm, int &tn) {
+        if (b_cw > 0) {
+            tm = b_tm;
+            tn = b_tn + b_cw * j;
+        } else {
+            const int id = first + j * stride;
+            tm = id / tiles_n;
+            tn = id - tm * tiles_n;
+        }
+    };
+    const int nph = p.K / W_BK;  // >= 4 and even (launcher)
+
+    // ---- DMA side: a 1-KiB piece = 16 rows x 64 B; wave w owns A pieces 4w..4w+3 and B pieces 4w..4w+3 of a slice.
+    const int prow = lane >> 2;
+    const int qsrc = (lane & 3) ^ ((0x78 >> (2 * ((prow >> 2) & 3))) & 3);  // source chunk of LDS position lane & 3
+    int dj = 0, dph = 0, dslot = 0;
+    uint32_t voa[4], vob[4];  // per-lane byte offsets (row, chunk) inside A / B (< 2^32: launcher)
+    auto dma_tile = [&](int j) {
+        int tm, tn;
+        tile_mn(j, tm, tn);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int gm = tm * W_BM + wave * 64 + i * 16 + prow;
+            gm = gm < p.M ? gm : p.M - 1;
+            voa[i] = ((uint32_t)gm * (uint32_t)p.lda + (uint32_t)(qsrc * 8)) * 2u;
+            int gn = tn * W_BN + wave * 64 + i * 16 + prow;
+            gn = gn < p.N ? gn : p.N - 1;
+            vob[i] = ((uint32_t)gn * (uint32_t)p.ldb + (uint32_t)(qsrc * 8)) * 2u;
+#ifdef PIO_GEMM_STAMPS
+            if constexpr (PIO_WIDE_ABL & 8) {  // timing only: every piece reads 1 KiB of CONTIGUOUS memory (8 full lines)
+                voa[i] = (uint32_t)((tm * 64 + wave * 4 + i) * 1024 + lane * 16);
+                vob[i] = (uint32_t)((tn * 64 + wave * 4 + i) * 1024 + lane * 16);
+            }
+#endif
+        }
+    };
+    const char *ia = nullptr, *ib = nullptr;  // wave-uniform bases: the DMA is "sgpr base + vgpr offset"
+    char *isb = nullptr;
+    int istep = 0, ibo = 0;
+    auto issue_begin = [&]() {
+        if (dj < ntl) {
+            ia = (const char *)((const T *)p.A + dph * W_BK);
+            ib = (const char *)((const T *)p.B + dph * W_BK);
+            isb = smem + dslot * W_STAGE + wave * 4096;
+            istep = 1024;
+            ibo = W_AB;
+        } else {  // past the end of the work: same number of pieces, into the sink
+            ia = (const char *)p.A;
+            ib = (const char *)p.B;
+            isb = smem + W_RING + wave * 1024;
+            istep = 0;
+            ibo = 0;
+        }
+    };
+    auto piece = [&](int i) {  // 0..3: A, 4..7: B
+        // (the offset is made opaque here so that its zero-extension is not hoisted out of the loop as a 64-bit
+        //  register pair: "uniform base + zext(32-bit VGPR)" at the use is what selects the SGPR-base form of the DMA)
+        uint32_t o = i < 4 ? voa[i] : vob[i - 4];
+        asm volatile("" : "+v"(o));
+        if (i < 4) wide_dma16(ia + (uint64_t)o, isb + i * istep);
+        else wide_dma16(ib + (uint64_t)o, isb + ibo + (i - 4) * istep);
+    };
+    auto issue_end = [&]() {
+        dslot = (dslot + 1) & 3;
+        if (dj < ntl && ++dph == nph) {
+            dph = 0;
+            if (++dj < ntl) dma_tile(dj);
+        }
+    };
+
+    // ---- MFMA side
+    const int fr = lane & 15, fq = lane >> 4;
+    auto fsw = [](int g) { return (0x78 >> (2 * (g & 3))) & 3; };
+    const int fa = fr * 64 + ((fq ^ fsw(fr >> 2)) << 4);
+    const int fb0 = (8 * (fr >> 2) + (fr & 3)) * 64 + ((fq ^ fsw(2 * (fr >> 2))) << 4);
+    const int fb1 = (8 * (fr >> 2) + 4 + (fr & 3)) * 64 + ((fq ^ fsw(2 * (fr >> 2) + 1)) << 4);
+    const int a_base = wm * 128 * 64, b_base = W_AB + wn * 128 * 64;
+    V8 af[2][8], bf[2][8];
+    f32x4 acc[8][8];
+
+    // ---- prologue: slices 0..3 in flight, slice 0 landed and in fragment set 0
+    dma_tile(0);
+#pragma unroll 1
+    for (int s = 0; s < 4; ++s) {
+        issue_begin();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) piece(i);
+        issue_end();
+    }
+    asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        af[0][i] = *(const V8 *)(smem + a_base + i * 1024 + fa);
+        bf[0][i] = *(const V8 *)(smem + b_base + (i >> 1) * 2048 + ((i & 1) ? fb1 : fb0));
+    }
+
+    int rslot = 1;      // ring slot of the slice whose fragments the next phase reads
+    // The bias row of a tile (this wave's 128 columns) is parked in LDS by ONE DMA at the start of the tile's first
+    // phase (no register held across the tile) and read back in the epilogue.
+    float *const bstash = (float *)(smem + W_BIAS + wave * 512);
+    int o_m = 0, o_n = 0, o_n0 = 0;  // this lane's first row / column of the current tile; the wave's first column
+    char *const sink = (char *)g_sink_w + lane * 16;
+
+    // One phase.  The wave is alone on its SIMD, so whatever it issues outside an MFMA's shadow idles the matrix pipe:
+    // the meeting point of the phase (counted wait for the DMA, wait for the LDS reads, barrier) sits BEHIND the
+    // phase's first eight MFMAs, which keep the pipe busy while the wave waits, and the scalar bookkeeping rides
+    // between MFMA groups.  `extra`: vector-memory operations issued between the last two phases' pieces and this
+    // phase's meeting point (the previous tile's 32 stores and this tile's bias DMA: first two phases of a tile).
+    auto phase = [&](auto PC, auto FC, int extra) {
+        constexpr int P = decltype(PC)::value;
+        constexpr bool FIRST = decltype(FC)::value;
+        const char *rb = smem + rslot * W_STAGE;
+        PIO_WSTAMP(0);
+        if constexpr (FIRST) {
+            if (lane < 32) {
+                const int n = o_n0 + lane * 4;
+                const float *src = (p.bias_mode == 1 && n < p.N) ? p.bias + n : (const float *)g_zero_w;
+                wide_dma16(src, bstash);
+            }
+        }
+        wide_for<0, 16>([&](auto GI) {
+            constexpr int g = decltype(GI)::value;
+#ifdef PIO_GEMM_STAMPS
+            constexpr bool skip_rd = PIO_WIDE_ABL & 1, skip_dma = PIO_WIDE_ABL & 2;
+#else
+            constexpr bool skip_rd = false, skip_dma = false;
+#endif
+            // DMA pieces ride behind groups 2, 4, ..., 14 and 15.  A piece costs the wave ~40 cycles of MFMA issue
+            // (8 pieces: 325 of a phase's ~1450 cycles; the 16 LDS reads cost 50) wherever it is put: issuing the four
+            // waves' pieces 16 cycles apart (tile loop compiled once per wave index) changed nothing, and a branch on
+            // the wave index between MFMAs costs far more than it saves.
+            constexpr int PIECE = (g >= 2 && !skip_dma) ? (g == 15 ? 7 : ((g & 1) == 0 ? (g - 2) >> 1 : -1)) : -1;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int mi = (4 * g + t) >> 3, ni = (4 * g + t) & 7;
+                if constexpr (FIRST) mfma_first<DT>(acc[mi][ni], bf[P][ni], af[P][mi]);
+                else mfma_acc<DT>(acc[mi][ni], bf[P][ni], af[P][mi]);
+                if (PIECE >= 0 && t == 3) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    piece(PIECE >= 0 ? PIECE : 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);  // (reads placed BEFORE the group's MFMAs would be waited for by them)
+            if constexpr (g == 0) issue_begin();
+            if constexpr (g == 1) {
+                // ---- meeting point.  All but the last two phases' pieces (+ extra) have landed: slice g+1 is complete
+                // in every wave's share; this wave's reads of slice g (issued in the previous phase) are done, so
+                // after the barrier slot g & 3 may be refilled (slice g+4) and slice g+1 may be read.
+                PIO_WSTAMP(1);
+                if (extra == 0) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                else if (extra == 1) asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(49)" ::: "memory");
+                PIO_WSTAMP(2);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                PIO_WSTAMP(3);
+#ifdef PIO_GEMM_STAMPS
+                if constexpr (!(PIO_WIDE_ABL & 4))
+#endif
+                __builtin_amdgcn_s_barrier();
+                PIO_WSTAMP(4);
+            }
+            if constexpr (g >= 2 && g < 6 && !skip_rd) {
+                af[P ^ 1][2 * (g - 2)] = *(const V8 *)(rb + a_base + (2 * (g - 2)) * 1024 + fa);
+                af[P ^ 1][2 * (g - 2) + 1] = *(const V8 *)(rb + a_base + (2 * (g - 2) + 1) * 1024 + fa);
+            } else if constexpr (g >= 6 && g < 10 && !skip_rd) {
+                bf[P ^ 1][2 * (g - 6)] = *(const V8 *)(rb + b_base + (g - 6) * 2048 + fb0);
+                bf[P ^ 1][2 * (g - 6) + 1] = *(const V8 *)(rb + b_base + (g - 6) * 2048 + fb1);
+            }
+            if constexpr (g == 15) {
+                issue_end();
+                rslot = (rslot + 1) & 3;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        PIO_WSTAMP(5);
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using Tt = std::true_type;
+    using Ff = std::false_type;
+
+    {
+#pragma unroll 1
+    for (int j = 0; j < ntl; ++j) {
+        {
+            int tm, tn;
+            tile_mn(j, tm, tn);
+            o_m = tm * W_BM + wm * 128 + fr;
+            o_n0 = tn * W_BN + wn * 128;
+            o_n = o_n0 + fq * 8;
+        }
+        phase(I0{}, Tt{}, j > 0 ? 33 : 1);
+        phase(I1{}, Ff{}, j > 0 ? 33 : 1);
+#pragma unroll 1
+        for (int ph = 2; ph < nph; ph += 2) {
+            phase(I0{}, Ff{}, 0);
+            phase(I1{}, Ff{}, 0);
+        }
+        // ---- exposed epilogue: 32 stores of 8 columns each
+#ifdef PIO_GEMM_STAMPS
+        if (blockIdx.x == 0 && threadIdx.x == 0) g_wstamps[6] = __builtin_readcyclecounter();
+#endif
+        T *const cbase = (T *)p.C;
+        const int t_m0 = o_m - (wm * 128 + fr), t_n0 = o_n0 - wn * 128;  // the tile's origin (wave-uniform)
+        if (t_m0 + W_BM <= p.M && t_n0 + W_BN <= p.N) {
+            // interior tile (every column < N <= n_store): one row pointer per mi, the four column groups are
+            // immediate offsets of the store
+            f32x4 b0[4], b1[4];
+#pragma unroll
+            for (int pp = 0; pp < 4; ++pp) {
+                b0[pp] = *(const f32x4 *)(bstash + pp * 32 + fq * 8);
+                b1[pp] = *(const f32x4 *)(bstash + pp * 32 + fq * 8 + 4);
+            }
+            char *crow = (char *)(cbase + (int64_t)o_m * p.ldc + o_n);
+            const int64_t rstep = (int64_t)p.ldc * 32;  // 16 rows, bytes
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi) {
+#pragma unroll
+                for (int pp = 0; pp < 4; ++pp) {
+                    V8 h;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        h[r] = Op<DT>::from_f32(acc_read(acc[mi][2 * pp][r]) * p.alpha + b0[pp][r]);
+                        h[4 + r] = Op<DT>::from_f32(acc_read(acc[mi][2 * pp + 1][r]) * p.alpha + b1[pp][r]);
+                    }
+                    *(V8 *)(crow + pp * 64) = h;
+                    __builtin_amdgcn_sched_barrier(0);  // (else all 256 accumulators are read out before the first store)
+                }
+                crow += rstep;
+            }
+        } else {
+        T *const cbase = (T *)p.C;
+    #pragma unroll
+            for (int pp = 0; pp < 4; ++pp) {
+                const int n = o_n + pp * 32;
+                const f32x4 b0 = *(const f32x4 *)(bstash + pp * 32 + fq * 8);
+                const f32x4 b1 = *(const f32x4 *)(bstash + pp * 32 + fq * 8 + 4);
+    #pragma unroll
+                for (int mi = 0; mi < 8; ++mi) {
+                    const int m = o_m + mi * 16;
+                    V8 h;
+    #pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        h[r] = Op<DT>::from_f32(acc_read(acc[mi][2 * pp][r]) * p.alpha + b0[r]);
+                        h[4 + r] = Op<DT>::from_f32(acc_read(acc[mi][2 * pp + 1][r]) * p.alpha + b1[r]);
+                    }
+                    if (n >= p.N) {
+    #pragma unroll
+                        for (int r = 0; r < 8; ++r) h[r] = Op<DT>::from_f32(0.f);  // columns [N, n_store): zeros
+                    }
+                    const bool ok = m < p.M && n < p.n_store;
+                    *(V8 *)(ok ? (char *)(cbase + (int64_t)m * p.ldc + n) : sink) = h;
+                    __builtin_amdgcn_sched_barrier(0);  // (else all 256 accumulators are read out before the first store)
+                }
+            }
+        }
+#ifdef PIO_GEMM_STAMPS
+        if (blockIdx.x == 0 && threadIdx.x == 0) g_wstamps[7] = __builtin_readcyclecounter();
+#endif
+    }
+    }
+#ifdef PIO_GEMM_STAMPS
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        g_wclk[2] = __builtin_amdgcn_s_memtime();
+        g_wclk[3] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
+}
+
+#ifdef PIO_GEMM_STAMPS
+extern "C" int pio_debug_wide_mode(void) { return PIO_WIDE_ABL; }
+extern "C" int pio_debug_wide_stamps(unsigned long long *out12) {
+    if (hipMemcpyFromSymbol(out12, HIP_SYMBOL(g_wstamps), sizeof(g_wstamps)) != hipSuccess) return 1;
+    return hipMemcpyFromSymbol(out12 + 8, HIP_SYMBOL(g_wclk), sizeof(g_wclk)) == hipSuccess ? 0 : 1;
+}
+#endif
+
+static int wide_grid(int64_t total) {
+    static const int n_cu = [] {
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        return n > 0 ? n : 256;
+    }();
+    int G = (int)(total < n_cu ? total : n_cu);
+    if (G >= 8) G &= ~7;
+    return G;
+}
+
+bool gemm_wide_ok(const GemmParams &p, int batch) {
+    if (batch != 1 || p.npass != 1) return false;
+    if (p.K < 4 * W_BK || (p.K % (2 * W_BK))) return false;
+    if (p.R || p.out_f32 || p.C_lo || p.act != 0) return false;
+    if (p.bias_mode > 1 || (p.bias_mode == 1 && !p.bias_vec)) return false;
+    if ((p.N & 7) || (p.n_store & 7) || (p.ldc & 7) || ((uintptr_t)p.C & 15)) return false;
+    if ((p.lda & 7) || (p.ldb & 7) || ((uintptr_t)p.A & 15) || ((uintptr_t)p.B & 15)) return false;
+    if (((int64_t)p.M * p.lda + p.K) * 2 >= (1ll << 32) || ((int64_t)p.N * p.ldb + p.K) * 2 >= (1ll << 32)) return false;
+    return true;
+}
+
+void gemm_wide_launch(const GemmParams &p, int dtype, hipStream_t s) {
+    const int tiles_m = (p.M + W_BM - 1) / W_BM, tiles_n = (p.n_store + W_BN - 1) / W_BN;
+    const int G = wide_grid((int64_t)tiles_m * tiles_n);
+    dim3 grid((unsigned)G, 1, 1), block(256, 1, 1);
+    if (dtype == PIO_DT_F16) hipLaunchKernelGGL((gemm_nt_wide<PIO_DT_F16>), grid, block, 0, s, p, tiles_m, tiles_n);
+    else hipLaunchKernelGGL((gemm_nt_wide<PIO_DT_BF16>), grid, block, 0, s, p, tiles_m, tiles_n);
+}
+
+}  // namespace pio

@@ -75,7 +75,8 @@ enum {
     PROF_FLASH = 5,
     PROF_GEMM_SMALL = 6,   // kernel gemm_nt_128<.,0> (flat problems too small / ragged for the 256 tile)
     PROF_GEMM_STREAM = 7,  // kernel gemm_nt_stream (persistent 256x128 tiles: the weight GEMMs of the latent stack)
-    PROF_CLASSES = 8
+    PROF_GEMM_WIDE = 8,    // kernel gemm_nt_wide (persistent 256x256 tiles, four waves: the fused q|k|v projection)
+    PROF_CLASSES = 9
 };
 struct ProfScope {
     int idx;

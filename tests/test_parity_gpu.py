@@ -152,10 +152,31 @@ STREAM_SHAPES = [
 ]
 
 
+WIDE_SHAPES = [
+    # (same fields; force = 2 selects the 256x256 four-wave kernel wherever it is legal)
+    (16384, 3072, 1024, 1, 1, 0, False, False, False, False, 0),   # the fused q|k|v projection: 768 tiles, blocked walk
+    (2048, 512, 128, 1, 1, 0, False, False, False, False, 2),      # shortest K (4 slices), 16 tiles on 16 workgroups
+    (3000, 776, 192, 1, 1, 0, False, False, False, False, 2),      # ragged M and N, 6 slices, 48 tiles
+    (5000, 2048, 320, 1, 0, 0, False, False, False, False, 2),     # no bias, 160 tiles on 160 WGs (linear walk)
+    (9000, 2304, 256, 1, 1, 0, False, False, False, False, 2),     # 324 tiles on 256 WGs: uneven lists, linear walk
+]
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("shape", WIDE_SHAPES)
+def test_gemm_nt_wide(dev, shape, dt):
+    """The persistent 256x256 four-wave kernel (pio_gemm_wide.hip) against torch fp64 on the same operands."""
+    _gemm_case(dev, shape, dt, shape[-1], "wide")
+
+
 @pytest.mark.parametrize("dt", ["f16", "bf16"])
 @pytest.mark.parametrize("shape", STREAM_SHAPES)
 def test_gemm_nt_stream(dev, shape, dt):
     """The persistent 256x128 streaming kernel (pio_gemm_stream.hip) against torch fp64 on the same operands."""
+    _gemm_case(dev, shape, dt, 1 if shape[-1] else 0, "stream")
+
+
+def _gemm_case(dev, shape, dt, override, what):
     from perceiverio_pytorch_amd import _lib as L
     lib = L.lib()
     M, N, K, batch, bias_mode, act, resid, out_f32, lo_w, lo_out, force = shape
@@ -185,7 +206,7 @@ def test_gemm_nt_stream(dev, shape, dt):
         gm.R, gm.ldr = Rm.data_ptr(), N
     gm.out_f32, gm.n_store = int(out_f32), ldc
     gm.dtype = L.PIO_DT_F16 if dt == "f16" else L.PIO_DT_BF16
-    prev = lib.pio_gemm_kernel_override(1 if force else 0)
+    prev = lib.pio_gemm_kernel_override(override)
     try:
         L.check(lib.pio_gemm_nt(C.byref(gm), torch.cuda.current_stream().cuda_stream), "pio_gemm_nt")
         torch.cuda.synchronize()
@@ -209,7 +230,7 @@ def test_gemm_nt_stream(dev, shape, dt):
     if lo_out and dt == "bf16":
         tol = 1e-4
     err = ((got[:, :, :N] - ref).abs().max() / ref.abs().max()).item()
-    assert err <= tol, f"stream gemm {shape} {dt}: {err:.3e}"
+    assert err <= tol, f"{what} gemm {shape} {dt}: {err:.3e}"
 
 
 @pytest.mark.parametrize("C_", [322, 1024, 261, 8, 1280])

@@ -21,7 +21,7 @@ with torch.inference_mode():
     L.check(lib.pio_prof_begin(4096))
     for _ in range(20):
         m(x)
-    ms = (C.c_double * 8)(); fl = (C.c_double * 8)(); by = (C.c_double * 8)(); ln = (C.c_int64 * 8)()
+    ms = (C.c_double * 9)(); fl = (C.c_double * 9)(); by = (C.c_double * 9)(); ln = (C.c_int64 * 9)()
     lib.pio_prof_end(ms, fl, by, ln)
 names = ["gemm256", "gemm128b", "ln", "softmax", "pack", "flash", "gemm128", "stream"]
 print(" ".join(f"{n}={ms[i] / ln[i] * 1e3:.1f}us(x{ln[i]})" for i, n in enumerate(names) if ln[i]), flush=True)

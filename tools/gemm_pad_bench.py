@@ -44,6 +44,14 @@ def run(M, N, K, pad, kernel, out_f32=False, resid=False, act=0, iters=30):
           f"{2.0 * M * N * K / us / 1e6:7.1f} TF/s", flush=True)
 
 
+if __name__ == "__main__" and "--wide" in sys.argv:
+    for kernel in (1, 2, 1, 2):
+        run(16384, 3072, 1024, 0, kernel)
+        run(16384, 1024, 1024, 0, kernel)
+        run(8192, 8192, 8192, 0, kernel, iters=5)
+        run(16384, 1024, 4096, 0, kernel)
+    sys.exit(0)
+
 if __name__ == "__main__":
     for kernel in (256, 1):
         pads = (0, 64) if "--pads" in sys.argv else (0,)

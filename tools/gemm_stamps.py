@@ -33,7 +33,7 @@ dev = torch.device("cuda:0")
 NAMES = {0: "full", 1: "no global stores", 2: "regs->global (no LDS pass)", 3: "no epilogue"}
 
 
-def run(M, N, K, out_f32, resid, act, mode, iters=20):
+def run(M, N, K, out_f32, resid, act, mode, iters=20, quiet=False):
     A = torch.randn(M, K, device=dev).half()
     B = (torch.randn(N, K, device=dev) / K ** 0.5).half()
     bias = torch.randn(N, device=dev)
@@ -60,6 +60,8 @@ def run(M, N, K, out_f32, resid, act, mode, iters=20):
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / iters * 1e3
+    if quiet:
+        return us
     s = (C.c_ulonglong * 8)()
     assert dbg(s, -1) == 0
     t = [int(v) for v in s]
@@ -94,6 +96,35 @@ def run_stream(M, N, K, out_f32, resid, act, iters=10, smode=0):
         print(f"   stream {what}: " + ", ".join(f"{n} {t[i + 1] - t[i]}" for i, n in enumerate(names) if n != "-") +
               f" | total {t[7] - t[0]}", flush=True)
 
+
+def run_clock(M, N, K, out_f32, resid, act, seconds=2.5):
+    """In-kernel clock of the streaming GEMM after `seconds` of back-to-back launches on random data:
+    d(s_memtime) / d(s_memrealtime) x 100 MHz around the last launch (workgroup 0)."""
+    cdbg = lib.pio_debug_stream_clock
+    cdbg.argtypes = [C.POINTER(C.c_ulonglong)]
+    assert lib.pio_debug_stream_mode(0) == 0
+    prev = lib.pio_gemm_kernel_override(1)
+    try:
+        us = run(M, N, K, out_f32, resid, act, 0, iters=20, quiet=True)
+        us = run(M, N, K, out_f32, resid, act, 0, iters=max(20, int(seconds * 1e6 / us)), quiet=True)
+    finally:
+        lib.pio_gemm_kernel_override(prev)
+    c = (C.c_ulonglong * 4)()
+    assert cdbg(c) == 0
+    cyc, ref = int(c[2]) - int(c[0]), int(c[3]) - int(c[1])
+    ghz = cyc / ref * 0.1
+    tf = 2.0 * M * N * K / us / 1e6
+    print(f"clock M={M} N={N} K={K} f32={int(out_f32)} R={int(resid)} act={act}: {us:7.1f} us {tf:7.1f} TF/s | kernel "
+          f"{cyc} cycles / {ref * 10} ns = {ghz:.3f} GHz held => MFMA peak at that clock {2500 * ghz / 2.4:6.0f} TF/s, "
+          f"achieved {tf / (2500 * ghz / 2.4) * 100:.1f} % of it", flush=True)
+
+
+if __name__ == "__main__" and "--clock" in sys.argv:
+    run_clock(16384, 3072, 1024, False, False, 0)
+    run_clock(16384, 1024, 1024, True, True, 0)
+    run_clock(16384, 1024, 1024, False, False, 1)
+    run_clock(8192, 8192, 8192, False, False, 0)
+    sys.exit(0)
 
 if __name__ == "__main__" and "--stream" in sys.argv:
     run_stream(16384, 1024, 1024, False, False, 0)

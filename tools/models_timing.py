@@ -28,7 +28,7 @@ def run(name, model, args, kwargs=None, n=3):
         ms_tot = (time.perf_counter() - t0) / n * 1e3
         L.check(lib.pio_prof_begin(20000))
         model(*args, **kwargs)
-        ms = (C.c_double * 8)(); fl = (C.c_double * 8)(); by = (C.c_double * 8)(); ln = (C.c_int64 * 8)()
+        ms = (C.c_double * 9)(); fl = (C.c_double * 9)(); by = (C.c_double * 9)(); ln = (C.c_int64 * 9)()
         lib.pio_prof_end(ms, fl, by, ln)
     parts = " ".join(f"{nm}={ms[i]:.2f}ms/{ln[i]}" + (f"({fl[i] / ms[i] / 1e9:.0f}TF)" if fl[i] else "")
                      for i, nm in enumerate(NAMES) if ln[i])

@@ -12,10 +12,11 @@ import perceiver_oracle as O  # noqa: E402
 
 
 class Rounder:
-    def __init__(self, dtype="f16", points=None, w_passes=2):
+    def __init__(self, dtype="f16", points=None, w_passes=2, fold=False):
         self.dtype = dtype
         self.points = points  # None = all
         self.w_passes = w_passes
+        self.fold = fold      # self-attend LayerNorms folded into the consuming GEMM
 
     def r16(self, x):
         if self.dtype == "f16":
@@ -73,7 +74,39 @@ def ln(x, p, name):
     return O.layer_norm(x, p[name + ".weight"].astype(np.float64), p[name + ".bias"].astype(np.float64))
 
 
+def lin_folded(x, p, ln_name, p_lin, name, rd):
+    """LN(x) W^T + b with the LayerNorm folded into the GEMM: the 16-bit operand is x itself, the weight is
+    gamma-scaled before rounding, and mean / rstd (exact row statistics) enter in the epilogue:
+    rs * (x16 W'^T - mu * rowsum(W')) + (W beta + b)."""
+    g, be = p[ln_name + ".weight"].astype(np.float64), p[ln_name + ".bias"].astype(np.float64)
+    w, b = p_lin[name + ".weight"].astype(np.float64), p_lin[name + ".bias"].astype(np.float64)
+    mu = x.mean(-1, keepdims=True)
+    rs = 1.0 / np.sqrt(x.var(-1, keepdims=True) + 1e-5)
+    wp = rd.weight(w * g[None, :])
+    return rs * (rd(x, "ln") @ wp.T - mu * wp.sum(1)[None, None, :]) + (w @ be + b)
+
+
+def self_attention_folded(p, x, H, rd):
+    pa = O._sub(p, "attention")
+    q = rd(lin_folded(x, p, "layer_norm1", pa, "proj_q", rd), "q")
+    k = rd(lin_folded(x, p, "layer_norm1", pa, "proj_k", rd), "k")
+    v = rd(lin_folded(x, p, "layer_norm1", pa, "proj_v", rd), "v")
+    B, T, qk = q.shape
+    dk, dv = qk // H, v.shape[2] // H
+    qh = q.reshape(B, T, H, dk).transpose(0, 2, 1, 3)
+    kh = k.reshape(B, T, H, dk).transpose(0, 2, 1, 3)
+    vh = v.reshape(B, T, H, dv).transpose(0, 2, 1, 3)
+    pr = rd(O.softmax_lastdim(qh @ kh.transpose(0, 1, 3, 2) / math.sqrt(dk)), "p")
+    o = rd((pr @ vh).transpose(0, 2, 1, 3).reshape(B, T, H * dv), "o")
+    x = x + lin(o, pa, "final", rd)
+    pm = O._sub(p, "mlp")
+    h = rd(O.gelu(lin_folded(x, p, "layer_norm2", pm, "fc1", rd)), "h")
+    return x + lin(h, pm, "fc2", rd)
+
+
 def self_attention(p, x, H, rd):
+    if rd.fold:
+        return self_attention_folded(p, x, H, rd)
     n = rd(ln(x, p, "layer_norm1"), "ln")
     x = x + attention(O._sub(p, "attention"), n, n, H, rd)
     return x + mlp(O._sub(p, "mlp"), rd(ln(x, p, "layer_norm2"), "ln"), rd)
@@ -122,6 +155,11 @@ if __name__ == "__main__":
     c64 = lambda d: {k: a.astype(np.float64) for k, a in d.items()}  # noqa: E731
     ref = O.encode_decode(c64(p_enc), c64(p_dec), x.astype(np.float64), qtab.astype(np.float64), **kw)
     allp = ["ln", "q", "k", "v", "p", "o", "h", "y", "w"]
+    if "--fold" in sys.argv:
+        for fold in (False, True):
+            y = encode_decode(p_enc, p_dec, x, qtab, Rounder("f16", None, 1, fold=fold), **kw)
+            print(f"{name} f16 w_passes=1 fold={fold}: relL2=%.2e max=%.2e" % O.rel_errors(y, ref), flush=True)
+        sys.exit(0)
     for dt in ("f16", "bf16"):
         for wp in (2, 1):
             y = encode_decode(p_enc, p_dec, x, qtab, Rounder(dt, None, wp), **kw)

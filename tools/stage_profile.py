@@ -13,7 +13,8 @@ lib = P.lib()
 B = 32
 x = torch.randn(B, 3136, 322, device=dev)
 pio = m.perceiver
-names = ["gemm_nt_256", "gemm_nt_128_batched", "layernorm_cast", "softmax", "pack", "flash_attn", "gemm_nt_128_flat"]
+names = ["gemm_nt_256", "gemm_nt_128_batched", "layernorm_cast", "softmax", "pack", "flash_attn", "gemm_nt_128_flat", "gemm_nt_stream",
+         "gemm_nt_wide"]
 with torch.inference_mode(), P.runtime.precision(pol):
     lat0 = pio._encoder.latents(x)
     z = pio._encoder.cross_attend(lat0, x)
@@ -24,7 +25,7 @@ with torch.inference_mode(), P.runtime.precision(pol):
     fn(); torch.cuda.synchronize()
     L.check(lib.pio_prof_begin(4096))
     for _ in range(3): fn()
-    ms = (C.c_double * 8)(); fl = (C.c_double * 8)(); by = (C.c_double * 8)(); ln = (C.c_int64 * 8)()
+    ms = (C.c_double * 9)(); fl = (C.c_double * 9)(); by = (C.c_double * 9)(); ln = (C.c_int64 * 9)()
     lib.pio_prof_end(ms, fl, by, ln)
 for i, n in enumerate(names):
     if ln[i]:
