@@ -14,7 +14,7 @@ with B = 32 per GPU.  Every decoder row is computed (as the reference does); the
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (one rank per GPU, RCCL)
 
 Rank 0 prints ONE JSON line.  Extra objects:
-  roofline     -- the dominant kernel (gemm_nt_stream, the weight GEMMs of the latent stack): ALGORITHMIC flops / device
+  roofline     -- the dominant kernel (gemm_nt_wide / gemm_nt_stream, the weight GEMMs of the latent stack): ALGORITHMIC flops / device
                   time measured with HIP events around every launch of that kernel in an instrumented repeat of the
                   step; `traffic` = HBM bytes per launch from the committed PMC profile (profiles/traffic.json)
   cpu_baseline -- the numpy oracle ("port") of the hot path timed on this host's cores on a bounded sample
@@ -255,8 +255,9 @@ def main():
                            "avg_us": ms[i] / ln[i] * 1e3,
                            "algo_tflops": (fl[i] / (ms[i] * 1e-3) / 1e12) if fl[i] else None,
                            "algo_gbps": by[i] / (ms[i] * 1e-3) / 1e9}
-    # the dominant kernel: the persistent streaming GEMM (class 7) carries the weight GEMMs of the latent stack
-    dom = 7 if ln[7] else 0
+    # the dominant kernel: the MFMA kernel class with the most device time per step (the persistent 256x256 GEMM with
+    # the fused q|k|v and fc1 projections of the latent stack, or the streaming GEMM with its out / fc2 projections)
+    dom = max((i for i in range(NCLS) if ln[i] and fl[i]), key=lambda i: ms[i])
     g = kernels[names[dom]]
     # HBM traffic of that kernel per launch: PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes of
     # this same command, gfx950 correction of MI355X_MICROARCH.md) condensed into profiles/traffic.json
@@ -266,8 +267,10 @@ def main():
             traffic = json.load(f)["pio::" + names[dom]]["bytes_per_launch"]
     except Exception:  # noqa: BLE001  (no committed profile yet)
         traffic = None
-    roofline = {"kernel": f"pio::{names[dom]} (weight GEMMs of the latent stack: out, fc1, fc2 projections; the fused "
-                          f"q|k|v projection runs on pio::gemm_nt_wide, see kernels)",
+    what = {"gemm_nt_wide": "16-bit-out weight GEMMs: fused q|k|v and fc1 (GELU) projections of the latent stack, decoder "
+                            "projections; the fp32 + residual out / fc2 projections run on pio::gemm_nt_stream, see kernels",
+            "gemm_nt_stream": "weight GEMMs of the latent stack"}.get(names[dom], "")
+    roofline = {"kernel": f"pio::{names[dom]} ({what})",
                 "bound": "mfma", "achieved": g["algo_tflops"], "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": g["algo_tflops"] / MFMA_PEAK_TFLOPS, "traffic": traffic,
                 "avg_launch_us": g["avg_us"], "launches_per_step": g["launches_per_step"],

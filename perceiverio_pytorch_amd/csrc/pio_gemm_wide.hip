@@ -104,7 +104,7 @@ __device__ __forceinline__ void mfma_first(f32x4 &c, typename Op<DT>::V8 a, type
     else asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(c) : "v"(a), "v"(b));
 }
 
-template <int DT>
+template <int DT, int ACT>
 __global__ __launch_bounds__(256) void gemm_nt_wide(const GemmParams p, int tiles_m, int tiles_n) {
     typedef typename Op<DT>::T T;
     typedef typename Op<DT>::V8 V8;
@@ -372,8 +372,14 @@ __global__ __launch_bounds__(256) void gemm_nt_wide(const GemmParams p, int tile
                     V8 h;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        h[r] = Op<DT>::from_f32(acc_read(acc[mi][2 * pp][r]) * p.alpha + b0[pp][r]);
-                        h[4 + r] = Op<DT>::from_f32(acc_read(acc[mi][2 * pp + 1][r]) * p.alpha + b1[pp][r]);
+                        float x0 = acc_read(acc[mi][2 * pp][r]) * p.alpha + b0[pp][r];
+                        float x1 = acc_read(acc[mi][2 * pp + 1][r]) * p.alpha + b1[pp][r];
+                        if constexpr (ACT == 1) {
+                            x0 = gelu_erf(x0);
+                            x1 = gelu_erf(x1);
+                        }
+                        h[r] = Op<DT>::from_f32(x0);
+                        h[4 + r] = Op<DT>::from_f32(x1);
                     }
                     *(V8 *)(crow + pp * 64) = h;
                     __builtin_amdgcn_sched_barrier(0);  // (else all 256 accumulators are read out before the first store)
@@ -393,8 +399,14 @@ __global__ __launch_bounds__(256) void gemm_nt_wide(const GemmParams p, int tile
                     V8 h;
     #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        h[r] = Op<DT>::from_f32(acc_read(acc[mi][2 * pp][r]) * p.alpha + b0[r]);
-                        h[4 + r] = Op<DT>::from_f32(acc_read(acc[mi][2 * pp + 1][r]) * p.alpha + b1[r]);
+                        float x0 = acc_read(acc[mi][2 * pp][r]) * p.alpha + b0[r];
+                        float x1 = acc_read(acc[mi][2 * pp + 1][r]) * p.alpha + b1[r];
+                        if constexpr (ACT == 1) {
+                            x0 = gelu_erf(x0);
+                            x1 = gelu_erf(x1);
+                        }
+                        h[r] = Op<DT>::from_f32(x0);
+                        h[4 + r] = Op<DT>::from_f32(x1);
                     }
                     if (n >= p.N) {
     #pragma unroll
@@ -441,7 +453,7 @@ static int wide_grid(int64_t total) {
 bool gemm_wide_ok(const GemmParams &p, int batch) {
     if (batch != 1 || p.npass != 1) return false;
     if (p.K < 4 * W_BK || (p.K % (2 * W_BK))) return false;
-    if (p.R || p.out_f32 || p.C_lo || p.act != 0) return false;
+    if (p.R || p.out_f32 || p.C_lo || (p.act != 0 && p.act != 1)) return false;
     if (p.bias_mode > 1 || (p.bias_mode == 1 && !p.bias_vec)) return false;
     if ((p.N & 7) || (p.n_store & 7) || (p.ldc & 7) || ((uintptr_t)p.C & 15)) return false;
     if ((p.lda & 7) || (p.ldb & 7) || ((uintptr_t)p.A & 15) || ((uintptr_t)p.B & 15)) return false;
@@ -453,8 +465,15 @@ void gemm_wide_launch(const GemmParams &p, int dtype, hipStream_t s) {
     const int tiles_m = (p.M + W_BM - 1) / W_BM, tiles_n = (p.n_store + W_BN - 1) / W_BN;
     const int G = wide_grid((int64_t)tiles_m * tiles_n);
     dim3 grid((unsigned)G, 1, 1), block(256, 1, 1);
-    if (dtype == PIO_DT_F16) hipLaunchKernelGGL((gemm_nt_wide<PIO_DT_F16>), grid, block, 0, s, p, tiles_m, tiles_n);
-    else hipLaunchKernelGGL((gemm_nt_wide<PIO_DT_BF16>), grid, block, 0, s, p, tiles_m, tiles_n);
+#define PIO_WK(DTV, ACT) hipLaunchKernelGGL((gemm_nt_wide<DTV, ACT>), grid, block, 0, s, p, tiles_m, tiles_n)
+    if (dtype == PIO_DT_F16) {
+        if (p.act == 1) PIO_WK(PIO_DT_F16, 1);
+        else PIO_WK(PIO_DT_F16, 0);
+    } else {
+        if (p.act == 1) PIO_WK(PIO_DT_BF16, 1);
+        else PIO_WK(PIO_DT_BF16, 0);
+    }
+#undef PIO_WK
 }
 
 }  // namespace pio

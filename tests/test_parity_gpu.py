@@ -159,6 +159,8 @@ WIDE_SHAPES = [
     (3000, 776, 192, 1, 1, 0, False, False, False, False, 2),      # ragged M and N, 6 slices, 48 tiles
     (5000, 2048, 320, 1, 0, 0, False, False, False, False, 2),     # no bias, 160 tiles on 160 WGs (linear walk)
     (9000, 2304, 256, 1, 1, 0, False, False, False, False, 2),     # 324 tiles on 256 WGs: uneven lists, linear walk
+    (16384, 1024, 1024, 1, 1, 1, False, False, False, False, 2),   # fc1: GELU in the exposed epilogue, 1 tile per WG
+    (2100, 520, 128, 1, 1, 1, False, False, False, False, 2),      # GELU on ragged edge tiles
 ]
 
 
