@@ -305,8 +305,10 @@ int gemm_nt_launch(const pio_gemm_t &g, hipStream_t s) {
         // at ~7 TB/s, and the GELU arithmetic hides behind them: 16384x1024x1024 takes 36 us (GELU: 42) against 42
         // (48) on the streaming kernel.  Override 2 forces it wherever it is legal.
         {
+            // (With a residual the kernel is legal but not chosen: the 64 MB residual read of a 16384x1024 launch is
+            //  exposed in its epilogue -- 49 us against 39 without -- where the streaming kernel hides most of it.)
             bool wide = g.batch == 1 && g.M >= 2048 && (double)tn256 * 256.0 <= 1.25 * p.n_store &&
-                        (int64_t)tm256 * tn256 >= 256;
+                        (int64_t)tm256 * tn256 >= 256 && !p.R;
             if (forced == 2) wide = true;
             if (forced == 1 || forced == 128 || forced == 256) wide = false;
             if (wide && gemm_wide_ok(p, g.batch)) {

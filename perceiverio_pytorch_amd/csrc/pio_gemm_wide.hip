@@ -104,7 +104,8 @@ __device__ __forceinline__ void mfma_first(f32x4 &c, typename Op<DT>::V8 a, type
     else asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(c) : "v"(a), "v"(b));
 }
 
-template <int DT, int ACT>
+// OUT: 0 = 16-bit C, 2 = fp32 C (optionally + residual R: HAS_R)
+template <int DT, int ACT, int OUT, bool HAS_R>
 __global__ __launch_bounds__(256) void gemm_nt_wide(const GemmParams p, int tiles_m, int tiles_n) {
     typedef typename Op<DT>::T T;
     typedef typename Op<DT>::V8 V8;
@@ -301,7 +302,8 @@ __global__ __launch_bounds__(256) void gemm_nt_wide(const GemmParams p, int tile
                 PIO_WSTAMP(1);
                 if (extra == 0) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
                 else if (extra == 1) asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(49)" ::: "memory");
+                else if (extra == 33) asm volatile("s_waitcnt vmcnt(49)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(63)" ::: "memory");  // (the counter's ceiling: stricter than needed)
                 PIO_WSTAMP(2);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 PIO_WSTAMP(3);
@@ -341,10 +343,15 @@ __global__ __launch_bounds__(256) void gemm_nt_wide(const GemmParams p, int tile
             o_n0 = tn * W_BN + wn * 128;
             o_n = o_n0 + fq * 8;
         }
-        phase(I0{}, Tt{}, j > 0 ? 33 : 1);
-        phase(I1{}, Ff{}, j > 0 ? 33 : 1);
+        constexpr int NSTORE = OUT == 2 ? 64 : 32;  // stores of one epilogue, per wave
+        // (phase g waits for the pieces of phase g-3: in phases 0..2 of a tile those are older than the previous
+        //  tile's stores, which may therefore stay outstanding; from phase 3 on the in-order counter makes them finish)
+        phase(I0{}, Tt{}, j > 0 ? NSTORE + 1 : 1);
+        phase(I1{}, Ff{}, j > 0 ? NSTORE + 1 : 1);
+        phase(I0{}, Ff{}, j > 0 ? NSTORE + 1 : 1);
+        phase(I1{}, Ff{}, 0);
 #pragma unroll 1
-        for (int ph = 2; ph < nph; ph += 2) {
+        for (int ph = 4; ph < nph; ph += 2) {
             phase(I0{}, Ff{}, 0);
             phase(I1{}, Ff{}, 0);
         }
@@ -352,9 +359,70 @@ __global__ __launch_bounds__(256) void gemm_nt_wide(const GemmParams p, int tile
 #ifdef PIO_GEMM_STAMPS
         if (blockIdx.x == 0 && threadIdx.x == 0) g_wstamps[6] = __builtin_readcyclecounter();
 #endif
-        T *const cbase = (T *)p.C;
         const int t_m0 = o_m - (wm * 128 + fr), t_n0 = o_n0 - wn * 128;  // the tile's origin (wave-uniform)
-        if (t_m0 + W_BM <= p.M && t_n0 + W_BN <= p.N) {
+        const bool interior = t_m0 + W_BM <= p.M && t_n0 + W_BN <= p.N;
+        if constexpr (OUT == 2) {
+            // fp32 out [+ residual]: 64 stores of 4 columns; the residual of row block mi+1 is loaded while block mi
+            // is converted and stored
+            float *const cf = (float *)p.C;
+            f32x4 b0[4], b1[4];
+#pragma unroll
+            for (int pp = 0; pp < 4; ++pp) {
+                b0[pp] = *(const f32x4 *)(bstash + pp * 32 + fq * 8);
+                b1[pp] = *(const f32x4 *)(bstash + pp * 32 + fq * 8 + 4);
+            }
+            const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+            f32x4 rb[2][8];
+            auto r_load = [&](int set, int mi) {
+                const int m = o_m + mi * 16;
+#pragma unroll
+                for (int pp = 0; pp < 4; ++pp) {
+                    const int n = o_n + pp * 32;
+                    if (interior || (m < p.M && n < p.N)) {
+                        const float *src = p.R + (int64_t)m * p.ldr + n;
+                        rb[set][2 * pp] = *(const f32x4 *)src;
+                        rb[set][2 * pp + 1] = *(const f32x4 *)(src + 4);
+                    } else {
+                        rb[set][2 * pp] = zero4;
+                        rb[set][2 * pp + 1] = zero4;
+                    }
+                }
+            };
+            if constexpr (HAS_R) r_load(0, 0);
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi) {
+                const int m = o_m + mi * 16;
+                if constexpr (HAS_R) {
+                    if (mi < 7) r_load((mi + 1) & 1, mi + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int pp = 0; pp < 4; ++pp) {
+                    const int n = o_n + pp * 32;
+                    f32x4 x0, x1;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        x0[r] = acc_read(acc[mi][2 * pp][r]) * p.alpha + b0[pp][r];
+                        x1[r] = acc_read(acc[mi][2 * pp + 1][r]) * p.alpha + b1[pp][r];
+                    }
+                    if constexpr (HAS_R) {
+                        x0 += rb[mi & 1][2 * pp];
+                        x1 += rb[mi & 1][2 * pp + 1];
+                    }
+                    if (!interior && n >= p.N) {
+                        x0 = zero4;  // columns [N, n_store): zeros
+                        x1 = zero4;
+                    }
+                    const bool ok = interior || (m < p.M && n < p.n_store);
+                    char *dst = ok ? (char *)(cf + (int64_t)m * p.ldc + n) : sink;
+                    *(f32x4 *)dst = x0;
+                    *(f32x4 *)(ok ? dst + 16 : dst) = x1;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        } else {
+        T *const cbase = (T *)p.C;
+        if (interior) {
             // interior tile (every column < N <= n_store): one row pointer per mi, the four column groups are
             // immediate offsets of the store
             f32x4 b0[4], b1[4];
@@ -418,6 +486,7 @@ __global__ __launch_bounds__(256) void gemm_nt_wide(const GemmParams p, int tile
                 }
             }
         }
+        }
 #ifdef PIO_GEMM_STAMPS
         if (blockIdx.x == 0 && threadIdx.x == 0) g_wstamps[7] = __builtin_readcyclecounter();
 #endif
@@ -453,7 +522,9 @@ static int wide_grid(int64_t total) {
 bool gemm_wide_ok(const GemmParams &p, int batch) {
     if (batch != 1 || p.npass != 1) return false;
     if (p.K < 4 * W_BK || (p.K % (2 * W_BK))) return false;
-    if (p.R || p.out_f32 || p.C_lo || (p.act != 0 && p.act != 1)) return false;
+    if (p.C_lo || (p.act != 0 && p.act != 1)) return false;
+    if (p.out_f32 && (p.act != 0 || (p.ldc & 3))) return false;
+    if (p.R && (!p.out_f32 || !p.r_vec || p.r_rows != 0 || (p.ldr & 3))) return false;
     if (p.bias_mode > 1 || (p.bias_mode == 1 && !p.bias_vec)) return false;
     if ((p.N & 7) || (p.n_store & 7) || (p.ldc & 7) || ((uintptr_t)p.C & 15)) return false;
     if ((p.lda & 7) || (p.ldb & 7) || ((uintptr_t)p.A & 15) || ((uintptr_t)p.B & 15)) return false;
@@ -465,14 +536,17 @@ void gemm_wide_launch(const GemmParams &p, int dtype, hipStream_t s) {
     const int tiles_m = (p.M + W_BM - 1) / W_BM, tiles_n = (p.n_store + W_BN - 1) / W_BN;
     const int G = wide_grid((int64_t)tiles_m * tiles_n);
     dim3 grid((unsigned)G, 1, 1), block(256, 1, 1);
-#define PIO_WK(DTV, ACT) hipLaunchKernelGGL((gemm_nt_wide<DTV, ACT>), grid, block, 0, s, p, tiles_m, tiles_n)
-    if (dtype == PIO_DT_F16) {
-        if (p.act == 1) PIO_WK(PIO_DT_F16, 1);
-        else PIO_WK(PIO_DT_F16, 0);
-    } else {
-        if (p.act == 1) PIO_WK(PIO_DT_BF16, 1);
-        else PIO_WK(PIO_DT_BF16, 0);
-    }
+#define PIO_WK(DTV, ACT, OUT, R) hipLaunchKernelGGL((gemm_nt_wide<DTV, ACT, OUT, R>), grid, block, 0, s, p, tiles_m, tiles_n)
+#define PIO_WS(DTV)                                   \
+    do {                                              \
+        if (p.out_f32 && p.R) PIO_WK(DTV, 0, 2, true); \
+        else if (p.out_f32) PIO_WK(DTV, 0, 2, false);  \
+        else if (p.act == 1) PIO_WK(DTV, 1, 0, false); \
+        else PIO_WK(DTV, 0, 0, false);                 \
+    } while (0)
+    if (dtype == PIO_DT_F16) PIO_WS(PIO_DT_F16);
+    else PIO_WS(PIO_DT_BF16);
+#undef PIO_WS
 #undef PIO_WK
 }
 

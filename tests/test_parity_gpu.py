@@ -161,6 +161,10 @@ WIDE_SHAPES = [
     (9000, 2304, 256, 1, 1, 0, False, False, False, False, 2),     # 324 tiles on 256 WGs: uneven lists, linear walk
     (16384, 1024, 1024, 1, 1, 1, False, False, False, False, 2),   # fc1: GELU in the exposed epilogue, 1 tile per WG
     (2100, 520, 128, 1, 1, 1, False, False, False, False, 2),      # GELU on ragged edge tiles
+    (16384, 1024, 1024, 1, 1, 0, True, True, False, False, 2),     # out / fc2: fp32 out + residual, 1 tile per WG
+    (3000, 776, 192, 1, 1, 0, True, True, False, False, 2),        # fp32 + residual on ragged edge tiles
+    (2048, 512, 128, 1, 0, 0, False, True, False, False, 2),       # fp32 out, no residual, no bias
+    (8192, 1024, 512, 1, 1, 0, True, True, False, False, 2),       # fp32 + residual, 128 tiles on 128 workgroups
 ]
 
 

@@ -49,6 +49,8 @@ if __name__ == "__main__" and "--wide" in sys.argv:
         run(16384, 3072, 1024, 0, kernel)
         run(16384, 1024, 1024, 0, kernel)
         run(16384, 1024, 1024, 0, kernel, act=1)
+        run(16384, 1024, 1024, 0, kernel, out_f32=True, resid=True)
+        run(16384, 1024, 1024, 0, kernel, out_f32=True)
         run(8192, 8192, 8192, 0, kernel, iters=5)
         run(16384, 1024, 4096, 0, kernel)
     sys.exit(0)
