@@ -49,9 +49,45 @@ def run(M, N, K, kernel, nsets, out_f32=False, resid=False, act=0, iters=48):
           f"{2.0 * M * N * K / us / 1e6:7.1f} TF/s", flush=True)
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and "--after-ln" not in sys.argv:
     for kernel in (1, 2):
         for nsets in (1, 8):
             run(16384, 3072, 1024, kernel, nsets)
             run(16384, 1024, 1024, kernel, nsets, act=1)
             run(16384, 1024, 1024, kernel, nsets, out_f32=True, resid=True)
+
+
+def run_after_ln(M, N, K, kernel, act, iters=40):
+    """The GEMM timed alone (events around each launch) when an unrelated kernel (LayerNorm + cast producing its A
+    operand) runs before every launch -- as in the model -- against the same GEMM back to back."""
+    from perceiverio_pytorch_amd import runtime as Rt
+    g, keep = make(M, N, K, False, False, act)
+    x = torch.randn(1, M, K, device=dev)
+    gamma = torch.ones(K, device=dev)
+    beta = torch.zeros(K, device=dev)
+    ln = L.LayerNorm(gamma.data_ptr(), beta.data_ptr(), K, 1e-5)
+    st = torch.cuda.current_stream().cuda_stream
+    prev = lib.pio_gemm_kernel_override(kernel)
+    try:
+        for mode in ("back to back", "after LayerNorm"):
+            tot = 0.0
+            for i in range(iters + 3):
+                if mode == "after LayerNorm":
+                    L.check(lib.pio_layernorm_cast(Rt.tensor3(x), C.byref(ln), keep[0].data_ptr(), None, K, L.PIO_DT_F16, st))
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                lib.pio_gemm_nt(C.byref(g), st)
+                e1.record()
+                torch.cuda.synchronize()
+                if i >= 3:
+                    tot += e0.elapsed_time(e1)
+            print(f"kernel={kernel} M={M} N={N} K={K} act={act} [{mode}]: {tot / iters * 1e3:7.1f} us", flush=True)
+    finally:
+        lib.pio_gemm_kernel_override(prev)
+
+
+if __name__ == "__main__" and "--after-ln" in sys.argv:
+    for kernel in (1, 2):
+        run_after_ln(16384, 1024, 1024, kernel, 1)
+        run_after_ln(16384, 1024, 1024, kernel, 0)
+        run_after_ln(16384, 3072, 1024, kernel, 0)
