@@ -183,6 +183,18 @@ typedef struct pio_gemm_t {
     int32_t out_f32;
     int32_t n_store;
     int32_t dtype;
+    /* LayerNorm folded into the GEMMs around it (optional; kernel gemm_nt_wide only, else PIO_E_SHAPE).
+     * Producer (fp32 out): X16 receives a 16-bit copy of the result (row stride ld16) and row_part, [M][N/128][2]
+     * fp32, the (sum, sum of squares) of every result row over each 128-column block (N % 128 == 0).
+     * Consumer (16-bit out, K == 1024): ln_part is the row_part a producer wrote for this GEMM's A operand and
+     * ln_c[n] = sum_k B[n,k]; the result is rstd_m * (A B^T)[m,n] - rstd_m * mean_m * ln_c[n] + bias[n] [GELU], i.e.
+     * LayerNorm(x) W^T + b for B = W * gamma, bias = W beta + b (transformer_primitives.py:281-292). */
+    void *X16;
+    int64_t ld16;
+    float *row_part;
+    const float *ln_part;
+    const float *ln_c;
+    float ln_eps;
 } pio_gemm_t;
 int pio_gemm_nt(const pio_gemm_t *g, void *stream);
 

@@ -71,7 +71,9 @@ class Gemm(C.Structure):
                 ("bias", C.c_void_p), ("bias_mode", C.c_int32), ("act", C.c_int32), ("alpha", C.c_float),
                 ("R", C.c_void_p), ("ldr", C.c_int64), ("r_stride_b", C.c_int64),
                 ("r_rows_per_batch", C.c_int32), ("out_f32", C.c_int32), ("n_store", C.c_int32),
-                ("dtype", C.c_int32)]
+                ("dtype", C.c_int32),
+                ("X16", C.c_void_p), ("ld16", C.c_int64), ("row_part", C.c_void_p), ("ln_part", C.c_void_p),
+                ("ln_c", C.c_void_p), ("ln_eps", C.c_float)]
 
 
 # name -> (restype, argtypes); must list EVERY function declared in include/pio_hip.h

@@ -231,6 +231,14 @@ static int &gemm_kernel_choice() {
     }();
     return choice;
 }
+// A/B switch for benchmarks: env PIO_GEMM_WIDE_R=1 sends residual GEMMs to the wide kernel as well
+static bool wide_residual() {
+    static const bool on = [] {
+        const char *e = getenv("PIO_GEMM_WIDE_R");
+        return e && atoi(e) != 0;
+    }();
+    return on;
+}
 int gemm_kernel_override(int which) {
     int &c = gemm_kernel_choice();
     const int prev = c;
@@ -272,6 +280,8 @@ int gemm_nt_launch(const pio_gemm_t &g, hipStream_t s) {
     // a residual whose batches are contiguous ([B, T, C] with stride_b == T * ld) is one flat [B*T, C] matrix
     if (p.R && p.r_rows > 0 && p.r_stride_b == (int64_t)p.r_rows * p.ldr) p.r_rows = 0;
     p.out_f32 = g.out_f32;
+    p.X16 = g.X16; p.ld16 = g.ld16; p.row_part = g.row_part;
+    p.ln_part = g.ln_part; p.ln_c = g.ln_c; p.ln_eps = g.ln_eps;
     p.n_store = g.n_store > g.N ? g.n_store : g.N;
     if (p.n_store > g.ldc) return PIO_E_SHAPE;
     p.tiles_n = (p.n_store + BN - 1) / BN;
@@ -308,9 +318,14 @@ int gemm_nt_launch(const pio_gemm_t &g, hipStream_t s) {
             // (With a residual the kernel is legal but not chosen: the 64 MB residual read of a 16384x1024 launch is
             //  exposed in its epilogue -- 49 us against 39 without -- where the streaming kernel hides most of it.)
             bool wide = g.batch == 1 && g.M >= 2048 && (double)tn256 * 256.0 <= 1.25 * p.n_store &&
-                        (int64_t)tm256 * tn256 >= 256 && !p.R;
+                        (int64_t)tm256 * tn256 >= 256 && (!p.R || wide_residual());
             if (forced == 2) wide = true;
             if (forced == 1 || forced == 128 || forced == 256) wide = false;
+            const bool fold = p.X16 || p.row_part || p.ln_part || p.ln_c;  // only this kernel implements the fold
+            if (fold) {
+                if (!gemm_wide_ok(p, g.batch)) return PIO_E_SHAPE;
+                wide = true;
+            }
             if (wide && gemm_wide_ok(p, g.batch)) {
                 ProfScope prof(PROF_GEMM_WIDE, algo_flops, algo_bytes, s);
                 gemm_wide_launch(p, g.dtype, s);

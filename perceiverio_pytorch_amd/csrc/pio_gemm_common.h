@@ -24,6 +24,12 @@ struct GemmParams {
     int vec_ok;    // C rows are 16-byte (fp32) / 8-byte (16-bit) aligned for 4-column vectors
     int r_vec;     // residual rows are 16-byte aligned
     int bias_vec;  // bias is 16-byte aligned
+    // LayerNorm fold (gemm_nt_wide only): producer outputs / consumer inputs, see pio_gemm_t
+    void *X16;
+    int64_t ld16;
+    float *row_part;
+    const float *ln_part, *ln_c;
+    float ln_eps;
 };
 
 

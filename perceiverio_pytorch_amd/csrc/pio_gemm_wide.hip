@@ -42,7 +42,7 @@ constexpr int W_AB = W_BM * W_BK * 2;    // 16 KiB of A per slice
 constexpr int W_STAGE = 2 * W_AB;        // 32 KiB
 constexpr int W_RING = W_NST * W_STAGE;  // 128 KiB
 constexpr int W_BIAS = W_RING + 4 * 1024;  // after the per-wave sinks for the pieces past the end: per-wave bias rows
-constexpr int W_SMEM = W_BIAS + 4 * 512;
+constexpr int W_SMEM = W_BIAS + 4 * 1024;  // per wave: bias row (512 B) + the LayerNorm fold's c row (512 B)
 
 static __device__ __attribute__((aligned(16))) uint32_t g_sink_w[64 * 4];
 static __device__ __attribute__((aligned(16))) uint32_t g_zero_w[4] = {0, 0, 0, 0};
@@ -104,8 +104,11 @@ __device__ __forceinline__ void mfma_first(f32x4 &c, typename Op<DT>::V8 a, type
     else asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(c) : "v"(a), "v"(b));
 }
 
-// OUT: 0 = 16-bit C, 2 = fp32 C (optionally + residual R: HAS_R)
-template <int DT, int ACT, int OUT, bool HAS_R>
+// OUT: 0 = 16-bit C, 2 = fp32 C (optionally + residual R: HAS_R).
+// LNF, the LayerNorm fold (pio_gemm_t): 1 = producer (OUT == 2): also stores a 16-bit copy of the result and per-row
+// partial (sum, sum of squares) per 128-column block; 2 = consumer (OUT == 0, K == 1024): the result is
+// rstd_m * acc - rstd_m * mean_m * c[n] + bias[n], with mean / rstd of row m of A from the producer's partial sums.
+template <int DT, int ACT, int OUT, bool HAS_R, int LNF>
 __global__ __launch_bounds__(256) void gemm_nt_wide(const GemmParams p, int tiles_m, int tiles_n) {
     typedef typename Op<DT>::T T;
     typedef typename Op<DT>::V8 V8;
@@ -206,8 +209,8 @@ __global__ __launch_bounds__(256) void gemm_nt_wide(const GemmParams p, int tile
     auto piece = [&](int i) {  // 0..3: A, 4..7: B
         // (the offset is made opaque here so that its zero-extension is not hoisted out of the loop as a 64-bit
         //  register pair: "uniform base + zext(32-bit VGPR)" at the use is what selects the SGPR-base form of the DMA)
-        uint32_t o = i < 4 ? voa[i] : vob[i - 4];
-        asm volatile("" : "+v"(o));
+        uint32_t &o = i < 4 ? voa[i] : vob[i - 4];
+        asm volatile("" : "+v"(o));  // (in place: no copy)
         if (i < 4) wide_dma16(ia + (uint64_t)o, isb + i * istep);
         else wide_dma16(ib + (uint64_t)o, isb + ibo + (i - 4) * istep);
     };
@@ -249,7 +252,8 @@ __global__ __launch_bounds__(256) void gemm_nt_wide(const GemmParams p, int tile
     int rslot = 1;      // ring slot of the slice whose fragments the next phase reads
     // The bias row of a tile (this wave's 128 columns) is parked in LDS by ONE DMA at the start of the tile's first
     // phase (no register held across the tile) and read back in the epilogue.
-    float *const bstash = (float *)(smem + W_BIAS + wave * 512);
+    float *const bstash = (float *)(smem + W_BIAS + wave * 1024);
+    float *const cstash = bstash + 128;
     int o_m = 0, o_n = 0, o_n0 = 0;  // this lane's first row / column of the current tile; the wave's first column
     char *const sink = (char *)g_sink_w + lane * 16;
 
@@ -268,6 +272,10 @@ __global__ __launch_bounds__(256) void gemm_nt_wide(const GemmParams p, int tile
                 const int n = o_n0 + lane * 4;
                 const float *src = (p.bias_mode == 1 && n < p.N) ? p.bias + n : (const float *)g_zero_w;
                 wide_dma16(src, bstash);
+                if constexpr (LNF == 2) {
+                    const float *srcc = n < p.N ? p.ln_c + n : (const float *)g_zero_w;
+                    wide_dma16(srcc, cstash);
+                }
             }
         }
         wide_for<0, 16>([&](auto GI) {
@@ -302,7 +310,9 @@ __global__ __launch_bounds__(256) void gemm_nt_wide(const GemmParams p, int tile
                 PIO_WSTAMP(1);
                 if (extra == 0) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
                 else if (extra == 1) asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
+                else if (extra == 2) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
                 else if (extra == 33) asm volatile("s_waitcnt vmcnt(49)" ::: "memory");
+                else if (extra == 34) asm volatile("s_waitcnt vmcnt(50)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(63)" ::: "memory");  // (the counter's ceiling: stricter than needed)
                 PIO_WSTAMP(2);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -343,12 +353,15 @@ __global__ __launch_bounds__(256) void gemm_nt_wide(const GemmParams p, int tile
             o_n0 = tn * W_BN + wn * 128;
             o_n = o_n0 + fq * 8;
         }
-        constexpr int NSTORE = OUT == 2 ? 64 : 32;  // stores of one epilogue, per wave
+        // stores of one epilogue per wave (a lower bound is enough once it exceeds the counter's ceiling) + the DMAs
+        // of the bias / c rows at the head of the tile's first phase
+        constexpr int NDMA0 = LNF == 2 ? 2 : 1;
+        constexpr int NSTORE = OUT == 2 ? 64 : 32;
         // (phase g waits for the pieces of phase g-3: in phases 0..2 of a tile those are older than the previous
         //  tile's stores, which may therefore stay outstanding; from phase 3 on the in-order counter makes them finish)
-        phase(I0{}, Tt{}, j > 0 ? NSTORE + 1 : 1);
-        phase(I1{}, Ff{}, j > 0 ? NSTORE + 1 : 1);
-        phase(I0{}, Ff{}, j > 0 ? NSTORE + 1 : 1);
+        phase(I0{}, Tt{}, j > 0 ? NSTORE + NDMA0 : NDMA0);
+        phase(I1{}, Ff{}, j > 0 ? NSTORE + NDMA0 : NDMA0);
+        phase(I0{}, Ff{}, j > 0 ? NSTORE + NDMA0 : NDMA0);
         phase(I1{}, Ff{}, 0);
 #pragma unroll 1
         for (int ph = 4; ph < nph; ph += 2) {
@@ -396,6 +409,7 @@ __global__ __launch_bounds__(256) void gemm_nt_wide(const GemmParams p, int tile
                     if (mi < 7) r_load((mi + 1) & 1, mi + 1);
                     __builtin_amdgcn_sched_barrier(0);
                 }
+                float rsum = 0.f, rsq = 0.f;  // (LNF == 1) this lane's share of row m: 32 columns
 #pragma unroll
                 for (int pp = 0; pp < 4; ++pp) {
                     const int n = o_n + pp * 32;
@@ -417,19 +431,84 @@ __global__ __launch_bounds__(256) void gemm_nt_wide(const GemmParams p, int tile
                     char *dst = ok ? (char *)(cf + (int64_t)m * p.ldc + n) : sink;
                     *(f32x4 *)dst = x0;
                     *(f32x4 *)(ok ? dst + 16 : dst) = x1;
+                    if constexpr (LNF == 1) {
+                        V8 h;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            rsum += x0[r] + x1[r];
+                            rsq += x0[r] * x0[r] + x1[r] * x1[r];
+                            h[r] = Op<DT>::from_f32(x0[r]);
+                            h[4 + r] = Op<DT>::from_f32(x1[r]);
+                        }
+                        *(V8 *)(ok ? (char *)((T *)p.X16 + (int64_t)m * p.ld16 + n) : sink) = h;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if constexpr (LNF == 1) {
+                    // the four lanes (fq = 0..3) of a row hold 32 columns each: two butterfly steps, then lane fq == 0
+                    // writes the row's (sum, sum of squares) over this wave's 128-column block
+                    rsum += __shfl_xor(rsum, 16);
+                    rsq += __shfl_xor(rsq, 16);
+                    rsum += __shfl_xor(rsum, 32);
+                    rsq += __shfl_xor(rsq, 32);
+                    if (fq == 0 && m < p.M && o_n0 < p.N) {
+                        float *dstp = p.row_part + ((int64_t)m * (p.N >> 7) + (o_n0 >> 7)) * 2;
+                        dstp[0] = rsum;
+                        dstp[1] = rsq;
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
         } else {
         T *const cbase = (T *)p.C;
+        // (LNF == 2) mean / rstd of this lane's eight rows from the producer's partial sums: lane group fq adds blocks
+        // 2 fq and 2 fq + 1 (K == 1024: eight 128-column blocks), two butterfly steps add the four groups
+        float rs[8], nmr[8];
+        if constexpr (LNF == 2) {
+            f32x4 part[8];
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi) {
+                int m = o_m + mi * 16;
+                m = m < p.M ? m : p.M - 1;
+                part[mi] = *(const f32x4 *)(p.ln_part + ((int64_t)m * 8 + 2 * fq) * 2);
+            }
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi) {
+                float sm = part[mi][0] + part[mi][2], sq = part[mi][1] + part[mi][3];
+                sm += __shfl_xor(sm, 16);
+                sq += __shfl_xor(sq, 16);
+                sm += __shfl_xor(sm, 32);
+                sq += __shfl_xor(sq, 32);
+                const float mean = sm * (1.0f / 1024.0f);
+                float var = sq * (1.0f / 1024.0f) - mean * mean;
+                var = var > 0.f ? var : 0.f;
+                rs[mi] = 1.0f / sqrtf(var + p.ln_eps);
+                nmr[mi] = -mean * rs[mi];
+            }
+        }
+        // one output element: alpha * acc + bias, or the folded LayerNorm form
+        auto val = [&](float a, float b, float c, int mi) {
+            float x;
+            if constexpr (LNF == 2) x = a * rs[mi] + (nmr[mi] * c + b);
+            else x = a * p.alpha + b;
+            if constexpr (ACT == 1) x = gelu_erf(x);
+            return x;
+        };
         if (interior) {
             // interior tile (every column < N <= n_store): one row pointer per mi, the four column groups are
             // immediate offsets of the store
-            f32x4 b0[4], b1[4];
+            f32x4 b0[4], b1[4], c0[4], c1[4];
 #pragma unroll
             for (int pp = 0; pp < 4; ++pp) {
                 b0[pp] = *(const f32x4 *)(bstash + pp * 32 + fq * 8);
                 b1[pp] = *(const f32x4 *)(bstash + pp * 32 + fq * 8 + 4);
+                if constexpr (LNF == 2) {
+                    c0[pp] = *(const f32x4 *)(cstash + pp * 32 + fq * 8);
+                    c1[pp] = *(const f32x4 *)(cstash + pp * 32 + fq * 8 + 4);
+                } else {
+                    c0[pp] = b0[pp];
+                    c1[pp] = b1[pp];
+                }
             }
             char *crow = (char *)(cbase + (int64_t)o_m * p.ldc + o_n);
             const int64_t rstep = (int64_t)p.ldc * 32;  // 16 rows, bytes
@@ -440,14 +519,8 @@ __global__ __launch_bounds__(256) void gemm_nt_wide(const GemmParams p, int tile
                     V8 h;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        float x0 = acc_read(acc[mi][2 * pp][r]) * p.alpha + b0[pp][r];
-                        float x1 = acc_read(acc[mi][2 * pp + 1][r]) * p.alpha + b1[pp][r];
-                        if constexpr (ACT == 1) {
-                            x0 = gelu_erf(x0);
-                            x1 = gelu_erf(x1);
-                        }
-                        h[r] = Op<DT>::from_f32(x0);
-                        h[4 + r] = Op<DT>::from_f32(x1);
+                        h[r] = Op<DT>::from_f32(val(acc_read(acc[mi][2 * pp][r]), b0[pp][r], c0[pp][r], mi));
+                        h[4 + r] = Op<DT>::from_f32(val(acc_read(acc[mi][2 * pp + 1][r]), b1[pp][r], c1[pp][r], mi));
                     }
                     *(V8 *)(crow + pp * 64) = h;
                     __builtin_amdgcn_sched_barrier(0);  // (else all 256 accumulators are read out before the first store)
@@ -461,20 +534,16 @@ __global__ __launch_bounds__(256) void gemm_nt_wide(const GemmParams p, int tile
                 const int n = o_n + pp * 32;
                 const f32x4 b0 = *(const f32x4 *)(bstash + pp * 32 + fq * 8);
                 const f32x4 b1 = *(const f32x4 *)(bstash + pp * 32 + fq * 8 + 4);
+                const f32x4 c0 = LNF == 2 ? *(const f32x4 *)(cstash + pp * 32 + fq * 8) : b0;
+                const f32x4 c1 = LNF == 2 ? *(const f32x4 *)(cstash + pp * 32 + fq * 8 + 4) : b1;
     #pragma unroll
                 for (int mi = 0; mi < 8; ++mi) {
                     const int m = o_m + mi * 16;
                     V8 h;
     #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        float x0 = acc_read(acc[mi][2 * pp][r]) * p.alpha + b0[r];
-                        float x1 = acc_read(acc[mi][2 * pp + 1][r]) * p.alpha + b1[r];
-                        if constexpr (ACT == 1) {
-                            x0 = gelu_erf(x0);
-                            x1 = gelu_erf(x1);
-                        }
-                        h[r] = Op<DT>::from_f32(x0);
-                        h[4 + r] = Op<DT>::from_f32(x1);
+                        h[r] = Op<DT>::from_f32(val(acc_read(acc[mi][2 * pp][r]), b0[r], c0[r], mi));
+                        h[4 + r] = Op<DT>::from_f32(val(acc_read(acc[mi][2 * pp + 1][r]), b1[r], c1[r], mi));
                     }
                     if (n >= p.N) {
     #pragma unroll
@@ -525,6 +594,16 @@ bool gemm_wide_ok(const GemmParams &p, int batch) {
     if (p.C_lo || (p.act != 0 && p.act != 1)) return false;
     if (p.out_f32 && (p.act != 0 || (p.ldc & 3))) return false;
     if (p.R && (!p.out_f32 || !p.r_vec || p.r_rows != 0 || (p.ldr & 3))) return false;
+    if (p.X16 || p.row_part) {  // LayerNorm-fold producer
+        if (!p.X16 || !p.row_part || !p.out_f32 || !p.R || (p.N & 127) || (p.ld16 & 7) || ((uintptr_t)p.X16 & 15) ||
+            ((uintptr_t)p.row_part & 7) || p.ln_part || p.ln_c)
+            return false;
+    }
+    if (p.ln_part || p.ln_c) {  // LayerNorm-fold consumer
+        if (!p.ln_part || !p.ln_c || p.out_f32 || p.K != 1024 || p.alpha != 1.0f || ((uintptr_t)p.ln_c & 15) ||
+            ((uintptr_t)p.ln_part & 15))
+            return false;
+    }
     if (p.bias_mode > 1 || (p.bias_mode == 1 && !p.bias_vec)) return false;
     if ((p.N & 7) || (p.n_store & 7) || (p.ldc & 7) || ((uintptr_t)p.C & 15)) return false;
     if ((p.lda & 7) || (p.ldb & 7) || ((uintptr_t)p.A & 15) || ((uintptr_t)p.B & 15)) return false;
@@ -536,13 +615,17 @@ void gemm_wide_launch(const GemmParams &p, int dtype, hipStream_t s) {
     const int tiles_m = (p.M + W_BM - 1) / W_BM, tiles_n = (p.n_store + W_BN - 1) / W_BN;
     const int G = wide_grid((int64_t)tiles_m * tiles_n);
     dim3 grid((unsigned)G, 1, 1), block(256, 1, 1);
-#define PIO_WK(DTV, ACT, OUT, R) hipLaunchKernelGGL((gemm_nt_wide<DTV, ACT, OUT, R>), grid, block, 0, s, p, tiles_m, tiles_n)
-#define PIO_WS(DTV)                                   \
-    do {                                              \
-        if (p.out_f32 && p.R) PIO_WK(DTV, 0, 2, true); \
-        else if (p.out_f32) PIO_WK(DTV, 0, 2, false);  \
-        else if (p.act == 1) PIO_WK(DTV, 1, 0, false); \
-        else PIO_WK(DTV, 0, 0, false);                 \
+#define PIO_WK(DTV, ACT, OUT, R, LNF) \
+    hipLaunchKernelGGL((gemm_nt_wide<DTV, ACT, OUT, R, LNF>), grid, block, 0, s, p, tiles_m, tiles_n)
+#define PIO_WS(DTV)                                                  \
+    do {                                                             \
+        if (p.row_part) PIO_WK(DTV, 0, 2, true, 1);                  \
+        else if (p.out_f32 && p.R) PIO_WK(DTV, 0, 2, true, 0);       \
+        else if (p.out_f32) PIO_WK(DTV, 0, 2, false, 0);             \
+        else if (p.ln_part && p.act == 1) PIO_WK(DTV, 1, 0, false, 2); \
+        else if (p.ln_part) PIO_WK(DTV, 0, 0, false, 2);             \
+        else if (p.act == 1) PIO_WK(DTV, 1, 0, false, 0);            \
+        else PIO_WK(DTV, 0, 0, false, 0);                            \
     } while (0)
     if (dtype == PIO_DT_F16) PIO_WS(PIO_DT_F16);
     else PIO_WS(PIO_DT_BF16);

@@ -603,3 +603,83 @@ def test_errors_are_loud(dev):
     m2 = SelfAttention(32, widening_factor=1, num_heads=4, dropout_prob=0.1).to(dev)
     with pytest.raises(NotImplementedError):
         m2(torch.zeros(1, 4, 32, device=dev))                     # training-mode dropout is not on this path
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("M,N2,act", [(4096, 3072, 0), (4000, 1024, 1), (16384, 1024, 1)])
+def test_gemm_layernorm_fold(dev, M, N2, act, dt):
+    """LayerNorm folded into the two GEMMs around it (pio_gemm_t.X16 / row_part -> ln_part / ln_c, kernel
+    gemm_nt_wide): x = R + A W1^T + b1 (fp32, + 16-bit copy + per-row partial sums), then
+    y = act(LN(x) W2^T + b2) computed as rstd * (x16 W'^T - mean * c) + b' -- against torch fp64 of the unfolded
+    chain (transformer_primitives.py:281-292)."""
+    from perceiverio_pytorch_amd import _lib as L
+    lib = L.lib()
+    D, K1 = 1024, 512
+    tdt = torch.float16 if dt == "f16" else torch.bfloat16
+    g = torch.Generator(device="cpu").manual_seed(M + N2 + act)
+    A = torch.randn(M, K1, generator=g).to(tdt).to(dev)
+    W1 = (torch.randn(D, K1, generator=g) / K1 ** 0.5).to(tdt).to(dev)
+    b1 = torch.randn(D, generator=g).to(dev)
+    Rm = (torch.randn(M, D, generator=g) * 2 + 0.3).to(dev)
+    gamma = (1 + 0.1 * torch.randn(D, generator=g)).to(dev)
+    beta = (0.1 * torch.randn(D, generator=g)).to(dev)
+    W2 = (torch.randn(N2, D, generator=g) / D ** 0.5).to(dev)
+    b2 = torch.randn(N2, generator=g).to(dev)
+    st = torch.cuda.current_stream().cuda_stream
+    code = L.PIO_DT_F16 if dt == "f16" else L.PIO_DT_BF16
+
+    # ---- producer
+    X = torch.full((M, D), float("nan"), device=dev)
+    X16 = torch.full((M, D), float("nan"), dtype=tdt, device=dev)
+    part = torch.full((M, D // 128, 2), float("nan"), device=dev)
+    gp = L.Gemm()
+    gp.A, gp.B, gp.C = A.data_ptr(), W1.data_ptr(), X.data_ptr()
+    gp.M, gp.N, gp.K = M, D, K1
+    gp.lda, gp.ldb, gp.ldc = K1, K1, D
+    gp.batch, gp.nh = 1, 1
+    gp.bias, gp.bias_mode, gp.act, gp.alpha = b1.data_ptr(), 1, 0, 1.0
+    gp.R, gp.ldr = Rm.data_ptr(), D
+    gp.out_f32, gp.n_store, gp.dtype = 1, D, code
+    gp.X16, gp.ld16, gp.row_part = X16.data_ptr(), D, part.data_ptr()
+    L.check(lib.pio_gemm_nt(C.byref(gp), st), "producer")
+    torch.cuda.synchronize()
+    xref = A.double() @ W1.double().T + b1.double() + Rm.double()
+    assert ((X.double() - xref).abs().max() / xref.abs().max()).item() <= 2e-5
+    assert torch.equal(X16, X.to(tdt)), "the 16-bit copy is the rounded fp32 result"
+    blocks = X.double().reshape(M, D // 128, 128)
+    assert torch.allclose(part[:, :, 0].double(), blocks.sum(-1), rtol=1e-4, atol=1e-3)
+    assert torch.allclose(part[:, :, 1].double(), (blocks * blocks).sum(-1), rtol=1e-4, atol=1e-3)
+
+    # ---- consumer
+    Wf = (W2 * gamma[None, :]).to(tdt)
+    cvec = Wf.float().sum(1).contiguous()
+    bf = (W2.double() @ beta.double() + b2.double()).float().contiguous()
+    ldc = N2
+    Y = torch.full((M, ldc), float("nan"), dtype=tdt, device=dev)
+    gc = L.Gemm()
+    gc.A, gc.B, gc.C = X16.data_ptr(), Wf.data_ptr(), Y.data_ptr()
+    gc.M, gc.N, gc.K = M, N2, D
+    gc.lda, gc.ldb, gc.ldc = D, D, ldc
+    gc.batch, gc.nh = 1, 1
+    gc.bias, gc.bias_mode, gc.act, gc.alpha = bf.data_ptr(), 1, act, 1.0
+    gc.out_f32, gc.n_store, gc.dtype = 0, N2, code
+    gc.ln_part, gc.ln_c, gc.ln_eps = part.data_ptr(), cvec.data_ptr(), 1e-5
+    L.check(lib.pio_gemm_nt(C.byref(gc), st), "consumer")
+    torch.cuda.synchronize()
+    xd = X.double()
+    ln = torch.nn.functional.layer_norm(xd, (D,), gamma.double(), beta.double(), 1e-5)
+    ref = ln @ W2.double().T + b2.double()
+    if act:
+        ref = torch.nn.functional.gelu(ref)
+    got = Y.double()
+    assert torch.isfinite(got).all()
+    err = ((got - ref).abs().max() / ref.abs().max()).item()
+    assert err <= (3e-3 if dt == "f16" else 2e-2), f"folded LayerNorm GEMM M={M} N={N2} act={act} {dt}: {err:.3e}"
+    # the same roundings in fp64: only the accumulation order and the 16-bit output rounding remain
+    mu = xd.mean(-1, keepdim=True)
+    rs = 1.0 / torch.sqrt(xd.var(-1, unbiased=False, keepdim=True) + 1e-5)
+    ref2 = rs * (X16.double() @ Wf.double().T - mu * cvec.double()[None, :]) + bf.double()[None, :]
+    if act:
+        ref2 = torch.nn.functional.gelu(ref2)
+    err2 = ((got - ref2).abs().max() / ref2.abs().max()).item()
+    assert err2 <= (1e-3 if dt == "f16" else 8e-3), f"folded LayerNorm GEMM vs same-rounding reference: {err2:.3e}"
