@@ -164,6 +164,21 @@ def main():
                   "ok": bool(rl2 <= 1e-3 and rmax <= 1e-3)}
         if not parity["ok"]:
             raise SystemExit(f"parity gate failed for policy {args.policy}: {parity}")
+        # The golden case has 1024 latent rows, below the 2048 from which the SelfAttention blocks fold their
+        # LayerNorms into the GEMMs (pio_ln_fold_t): check THIS run's batch against the same model under the
+        # float32-grade policy fp16x3 (three MFMA sweeps, no fold; 2e-6 against the reference on the golden case)
+        if not args.hot_path_only and args.policy != "fp16x3":
+            with torch.inference_mode():
+                y_run = model(x).double()
+                model.precision_policy = "fp16x3"
+                y_ref = model(x).double()
+                model.precision_policy = args.policy
+            frel = float(((y_run - y_ref).norm() / y_ref.norm()).item())
+            fold_on = lib.pio_ln_fold_enable(1)     # (returns the previous setting: read it and put it back)
+            lib.pio_ln_fold_enable(fold_on)
+            parity["bench_batch_vs_fp16x3"] = {"relL2": frel, "tol": 1e-3, "batch": B, "layernorm_fold": bool(fold_on)}
+            if frel > 1e-3:
+                raise SystemExit(f"parity gate failed on the benchmarked batch: {parity}")
 
     gathered = [torch.empty(B, CFG["out"], device=dev) for _ in range(world)] if world > 1 else None
 
@@ -224,8 +239,10 @@ def main():
                 return e0.elapsed_time(e1) / n
 
             t_cross = timed(lambda: enc.cross_attend(lat0, xin))
-            z1 = enc.cross_attend(lat0, xin)
-            t_sa = timed(lambda: enc.self_attends[0](z1))
+            # one self-attend layer as it runs INSIDE the stack (row statistics of the LayerNorm fold carried from
+            # block to block): (whole encoder - its cross-attend) / layers
+            t_enc = timed(lambda: enc(xin, lat0), n=3)
+            t_sa = (t_enc - t_cross) / (CFG["L"] * CFG["blocks"])
             zf = enc(xin, lat0)
             qtab_ = pio._output_queries["__default"]._position_encoding.pos_embs
             qv = torch.broadcast_to(qtab_[None], (B,) + qtab_.shape)
@@ -267,8 +284,8 @@ def main():
             traffic = json.load(f)["pio::" + names[dom]]["bytes_per_launch"]
     except Exception:  # noqa: BLE001  (no committed profile yet)
         traffic = None
-    what = {"gemm_nt_wide": "16-bit-out weight GEMMs: fused q|k|v and fc1 (GELU) projections of the latent stack, decoder "
-                            "projections; the fp32 + residual out / fc2 projections run on pio::gemm_nt_stream, see kernels",
+    what = {"gemm_nt_wide": "the weight GEMMs of the latent stack: fused q|k|v, out, fc1 (GELU), fc2 projections with the "
+                            "LayerNorms folded into them, and the decoder projections",
             "gemm_nt_stream": "weight GEMMs of the latent stack"}.get(names[dom], "")
     roofline = {"kernel": f"pio::{names[dom]} ({what})",
                 "bound": "mfma", "achieved": g["algo_tflops"], "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",

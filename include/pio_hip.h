@@ -90,11 +90,25 @@ typedef struct pio_mlp_t {
     int32_t act_split;
 } pio_mlp_t;
 
+/* Optional LayerNorm fold of a SelfAttention block (all pointers NULL = not available): the two GEMMs that
+ * consume a LayerNorm output take the un-normalised 16-bit activations instead and apply mean / rstd in their
+ * epilogue; the GEMMs that produce the LayerNorm input leave the row statistics (pio_gemm_t.X16 / row_part).
+ * qkv: [q | k | v] rows packed from W * gamma1 with bias W beta1 + b; fc1: from W1 * gamma2, bias W1 beta2 + b1;
+ * *_c[n] = sum_k of the packed 16-bit weights of row n.  Used for 1024-channel blocks under the single-sweep
+ * policies when the block has at least 2048 rows and no mask / bias / probabilities are requested. */
+typedef struct pio_ln_fold_t {
+    pio_linear_t qkv;
+    const float *qkv_c;
+    pio_linear_t fc1;
+    const float *fc1_c;
+} pio_ln_fold_t;
+
 /* SelfAttention (transformer_primitives.py:219-297) */
 typedef struct pio_self_attention_t {
     pio_layernorm_t ln1, ln2;
     pio_attention_t attn;
     pio_mlp_t mlp;
+    pio_ln_fold_t fold;
 } pio_self_attention_t;
 
 /* CrossAttention (transformer_primitives.py:300-406) */
@@ -130,6 +144,11 @@ int pio_prof_begin(int32_t max_records);
  * (2*M*N*K per product, extra precision sweeps not counted), algorithmic bytes, launch count.
  * Arrays have PIO_PROF_CLASSES entries (any may be NULL).  Returns the number of records or <0. */
 int pio_prof_end(double *ms, double *flops, double *bytes, int64_t *launches);
+
+/* --- LayerNorm fold of the SelfAttention blocks (pio_ln_fold_t), for tests and A/B benchmarks ------ */
+/* 1: use the fold wherever a block offers it (default; env PIO_LN_FOLD gives the initial value), 0: never.
+ * Returns the previous setting. */
+int pio_ln_fold_enable(int on);
 
 /* --- kernel selection of pio_gemm_nt, for tests and A/B benchmarks ------------------------------- */
 /* 0: automatic (default; env PIO_GEMM_TILE gives the initial value), 128: 128x128 tile, 256: 256x256 tile,

@@ -46,8 +46,12 @@ class Mlp(C.Structure):
                 ("dtype", C.c_int32), ("act_split", C.c_int32)]
 
 
+class LnFold(C.Structure):
+    _fields_ = [("qkv", Linear), ("qkv_c", C.c_void_p), ("fc1", Linear), ("fc1_c", C.c_void_p)]
+
+
 class SelfAttention(C.Structure):
-    _fields_ = [("ln1", LayerNorm), ("ln2", LayerNorm), ("attn", Attention), ("mlp", Mlp)]
+    _fields_ = [("ln1", LayerNorm), ("ln2", LayerNorm), ("attn", Attention), ("mlp", Mlp), ("fold", LnFold)]
 
 
 class CrossAttention(C.Structure):
@@ -88,6 +92,7 @@ SIGNATURES = {
     "pio_prof_end": (C.c_int, [P(C.c_double), P(C.c_double), P(C.c_double), P(C.c_int64)]),
     "pio_pad8": (_i32, [_i32]),
     "pio_gemm_kernel_override": (C.c_int, [C.c_int]),
+    "pio_ln_fold_enable": (C.c_int, [C.c_int]),
     "pio_packed_weight_bytes": (_sz, [_i32, _i32, _i32, _i32]),
     "pio_pack_linear": (C.c_int, [_vp, _vp, _i32, _i32, _i64, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "pio_layernorm_cast": (C.c_int, [P(Tensor3), P(LayerNorm), _vp, _vp, _i32, _i32, _vp]),

@@ -55,10 +55,35 @@ static pio_gemm_t gemm_defaults(int dtype) {
     return g;
 }
 
+// LayerNorm fold plumbing of one GEMM (pio_ln_fold_t; all null = plain GEMM).  Consumer side: the 16-bit input is the
+// UN-normalised activation and `in_part` its per-row partial sums -- the GEMM then uses the folded weights `w` / row
+// sums `c`.  Producer side: where the (fp32 + residual) GEMM leaves the 16-bit copy and the partial sums of its result.
+struct LnFold {
+    const float *in_part = nullptr;
+    const pio_linear_t *w = nullptr;
+    const float *c = nullptr;
+    float eps = 0.f;
+    void *out16 = nullptr;
+    int64_t ld16 = 0;
+    float *out_part = nullptr;
+};
+
 // y[rows, n] = x16[rows, lin.k] * W^T (+bias) (act) (+R); a 16-bit output has ldc = lin.n (padded).
-static int linear_fwd(const pio_linear_t &lin, int dtype, Pair x, int64_t rows, void *y, void *y_lo, bool out_f32,
-                      int n_logical, int64_t ldc, int act, const Residual *res, hipStream_t s) {
+static int linear_fwd(const pio_linear_t &lin_plain, int dtype, Pair x, int64_t rows, void *y, void *y_lo, bool out_f32,
+                      int n_logical, int64_t ldc, int act, const Residual *res, hipStream_t s,
+                      const LnFold *fold = nullptr) {
+    const pio_linear_t &lin = (fold && fold->in_part) ? *fold->w : lin_plain;
     pio_gemm_t g = gemm_defaults(dtype);
+    if (fold && fold->in_part) {
+        g.ln_part = fold->in_part;
+        g.ln_c = fold->c;
+        g.ln_eps = fold->eps;
+    }
+    if (fold && fold->out16) {
+        g.X16 = fold->out16;
+        g.ld16 = fold->ld16;
+        g.row_part = fold->out_part;
+    }
     g.A = x.hi;
     g.A_lo = x.lo;
     g.B = lin.w_hi;
@@ -121,7 +146,8 @@ static int check_attention(const pio_attention_t &a) {
 static int attention_core(const pio_attention_t &a, Pair xq, bool q_bcast, Pair xk, Pair xv, int B, int Tq, int Tk,
                           const uint8_t *kv_mask, const uint8_t *q_mask, const uint8_t *full_mask,
                           const float *attention_bias, const Residual *res, float *out, float *probs_out,
-                          AttnScratch &w, hipStream_t s) {
+                          AttnScratch &w, hipStream_t s, const LnFold *fold_in = nullptr,
+                          const LnFold *fold_out = nullptr) {
     PIO_TRY(check_attention(a));
     const int H = a.heads;
     const int64_t hdk = (int64_t)H * a.dkp, ldo = (int64_t)H * a.dvp, tkp = pad8(Tk);
@@ -140,13 +166,16 @@ static int attention_core(const pio_attention_t &a, Pair xq, bool q_bcast, Pair 
                               (char *)w.vt16.hi == (char *)w.k16.hi + third;
         if (fuse_qkv) {
             const int64_t ld3 = 3 * hdk;
-            PIO_TRY(linear_fwd(a.qkv, a.dtype, xq, (int64_t)B * Tq, w.q16.hi, nullptr, false, 0, ld3, 0, nullptr, s));
+            PIO_TRY(linear_fwd(a.qkv, a.dtype, xq, (int64_t)B * Tq, w.q16.hi, nullptr, false, 0, ld3, 0, nullptr, s,
+                               fold_in));
             const char *base = (const char *)w.q16.hi;
             PIO_TRY(flash_attention_launch(a.dtype, 128, 128, a.dk, base, base + hdk * 2, base + 2 * hdk * 2,
                                            w.o16.hi, B, H, Tq, Tk, ld3, ld3, ld3, ldo, (int64_t)Tq * ld3,
                                            (int64_t)Tk * ld3, (int64_t)Tk * ld3, (int64_t)Tq * ldo, true, s));
-            return linear_fwd(a.o, a.dtype, w.o16, (int64_t)B * Tq, out, nullptr, true, a.out, a.out, 0, res, s);
+            return linear_fwd(a.o, a.dtype, w.o16, (int64_t)B * Tq, out, nullptr, true, a.out, a.out, 0, res, s,
+                              fold_out);
         }
+        if (fold_in || fold_out) return PIO_E_SHAPE;  // the fold is wired into the fused q|k|v form only
     }
 
     // 1/2: Q and K projections (transformer_primitives.py:93-94), head-padded columns.  When both read the same
@@ -261,11 +290,11 @@ static int attention_core(const pio_attention_t &a, Pair xq, bool q_bcast, Pair 
 // MLP core on a 16-bit input
 // ------------------------------------------------------------------------------------------------------
 static int mlp_core(const pio_mlp_t &m, Pair x, int64_t rows, Pair h, const Residual *res, float *out,
-                    hipStream_t s) {
+                    hipStream_t s, const LnFold *fold_in = nullptr, const LnFold *fold_out = nullptr) {
     if (m.fc1.k != pad8(m.in) || m.fc1.n != pad8(m.hidden) || m.fc2.k != m.fc1.n) return PIO_E_SHAPE;
     if (m.act_split && (!m.fc1.w_lo || !m.fc2.w_lo)) return PIO_E_ARG;
-    PIO_TRY(linear_fwd(m.fc1, m.dtype, x, rows, h.hi, h.lo, false, 0, m.fc1.n, 1, nullptr, s));
-    return linear_fwd(m.fc2, m.dtype, h, rows, out, nullptr, true, m.out, m.out, 0, res, s);
+    PIO_TRY(linear_fwd(m.fc1, m.dtype, x, rows, h.hi, h.lo, false, 0, m.fc1.n, 1, nullptr, s, fold_in));
+    return linear_fwd(m.fc2, m.dtype, h, rows, out, nullptr, true, m.out, m.out, 0, res, s, fold_out);
 }
 
 // ======================================================================================================
@@ -306,6 +335,10 @@ struct SelfPlan {
     Pair x16, h16;
     float *x1;
     AttnScratch core;
+    // LayerNorm fold (pio_ln_fold_t): 16-bit copy of x1 and the per-row partial sums of x (A) and x1 (B); the 16-bit
+    // copy of x lives in x16
+    void *x16b = nullptr;
+    float *part_a = nullptr, *part_b = nullptr;
     size_t carve(void *base, const pio_self_attention_t &sa, int B, int N) {
         Carver c(base);
         const int64_t rows = (int64_t)B * N;
@@ -314,18 +347,81 @@ struct SelfPlan {
         h16 = take_pair(c, (size_t)rows * pad8(sa.mlp.hidden), sa.mlp.act_split != 0);
         x1 = (float *)c.take((size_t)rows * sa.attn.out * 4);
         core.carve(c, sa.attn, B, B, N, N);
+        if (sa.fold.qkv.w_hi && sa.fold.fc1.w_hi) {
+            x16b = c.take((size_t)rows * cmax * 2);
+            part_a = (float *)c.take((size_t)rows * 8 * 2 * 4);
+            part_b = (float *)c.take((size_t)rows * 8 * 2 * 4);
+        }
         return c.off;
     }
 };
 
+// LayerNorm fold switch (pio_ln_fold_enable; initial value from env PIO_LN_FOLD, default on)
+static int &ln_fold_choice() {
+    static int choice = [] {
+        const char *e = getenv("PIO_LN_FOLD");
+        return e ? (atoi(e) != 0 ? 1 : 0) : 1;
+    }();
+    return choice;
+}
+int ln_fold_enable(int on) {
+    int &c = ln_fold_choice();
+    const int prev = c;
+    c = on ? 1 : 0;
+    return prev;
+}
+bool ln_fold_enabled() { return ln_fold_choice() != 0; }
+
+// Carried from one SelfAttention block to the next inside a stack: the 16-bit copy and the partial sums of the block's
+// INPUT, left in the plan's (x16, part_a) buffers by the previous block's fc2 GEMM.
+struct FoldCarry {
+    const void *x = nullptr;  // the fp32 tensor they describe
+    const void *x16 = nullptr;
+    const float *part = nullptr;
+};
+
 static int self_attention_run(const pio_self_attention_t &sa, const pio_tensor3_t &x, const uint8_t *kv_mask,
                               const uint8_t *q_mask, const uint8_t *full_mask, const float *attention_bias,
-                              float *out, float *probs_out, SelfPlan &p, hipStream_t s) {
+                              float *out, float *probs_out, SelfPlan &p, hipStream_t s, FoldCarry *carry = nullptr) {
     const int B = x.B, N = x.T;
     const int64_t rows = (int64_t)B * N;
     if (x.C != sa.attn.q_in || sa.attn.k_in != x.C || sa.attn.v_in != x.C || sa.attn.out != x.C ||
         sa.mlp.in != x.C || sa.mlp.out != x.C)
         return PIO_E_SHAPE;  // residual adds need matching widths (the reference raises a RuntimeError)
+    // LayerNorm fold: 1024-channel contiguous rows, single-sweep operands, the fused q|k|v form, enough rows for the
+    // 256x256-tile kernel to fill the chip, nothing that needs the score matrix
+    const bool fold = ln_fold_enabled() && p.x16b && x.C == 1024 && rows >= 2048 && x.stride_t == x.C &&
+                      (B == 1 || x.stride_b == (int64_t)N * x.C) && !sa.attn.act_split && !sa.mlp.act_split &&
+                      sa.attn.qkv.w_hi && !sa.attn.qkv.w_lo && !sa.mlp.fc1.w_lo && !sa.mlp.fc2.w_lo && !sa.attn.o.w_lo &&
+                      sa.attn.dkp == 128 && sa.attn.dvp == 128 && sa.fold.qkv.n == sa.attn.qkv.n &&
+                      sa.fold.qkv.k == 1024 && sa.fold.fc1.k == 1024 && sa.fold.fc1.n == sa.mlp.fc1.n &&
+                      sa.mlp.dtype == sa.attn.dtype && !kv_mask && !q_mask && !full_mask && !attention_bias &&
+                      !probs_out && (((uintptr_t)x.data) & 15) == 0;
+    if (fold) {
+        // x16 / part_a: the block input (from the previous block's fc2, or computed here for the first block)
+        if (!(carry && carry->x == x.data && carry->x16 == p.x16.hi && carry->part == p.part_a))
+            PIO_TRY(rowstats_cast_launch(x.data, rows, p.x16.hi, p.part_a, sa.attn.dtype, s));
+        const Pair xa = {p.x16.hi, nullptr};
+        LnFold f_qkv, f_out, f_fc1, f_fc2;
+        f_qkv.in_part = p.part_a; f_qkv.w = &sa.fold.qkv; f_qkv.c = sa.fold.qkv_c; f_qkv.eps = sa.ln1.eps;
+        f_out.out16 = p.x16b; f_out.ld16 = x.C; f_out.out_part = p.part_b;
+        f_fc1.in_part = p.part_b; f_fc1.w = &sa.fold.fc1; f_fc1.c = sa.fold.fc1_c; f_fc1.eps = sa.ln2.eps;
+        f_fc2.out16 = p.x16.hi; f_fc2.ld16 = x.C; f_fc2.out_part = p.part_a;
+        const Residual rx = residual_of(x);
+        PIO_TRY(attention_core(sa.attn, xa, false, xa, xa, B, N, N, nullptr, nullptr, nullptr, nullptr, &rx, p.x1,
+                               nullptr, p.core, s, &f_qkv, &f_out));
+        pio_tensor3_t t1 = {p.x1, (int64_t)N * x.C, x.C, B, N, x.C};
+        const Pair xm = {p.x16b, nullptr};
+        const Residual r1 = residual_of(t1);
+        PIO_TRY(mlp_core(sa.mlp, xm, rows, p.h16, &r1, out, s, &f_fc1, &f_fc2));
+        if (carry) {
+            carry->x = out;
+            carry->x16 = p.x16.hi;
+            carry->part = p.part_a;
+        }
+        return PIO_OK;
+    }
+    if (carry) *carry = FoldCarry();
     // LN1 -> attention -> + x     (transformer_primitives.py:281-290)
     const Pair xa = pair_if(p.x16, sa.attn.act_split);
     PIO_TRY(cast_pair(x, &sa.ln1, xa, pad8(x.C), sa.attn.dtype, s));
@@ -465,6 +561,8 @@ int pio_mlp_fwd(const pio_mlp_t *m, const pio_tensor3_t *x, float *out, void *wo
 // ======================================================================================================
 // SelfAttention.forward / CrossAttention.forward
 // ======================================================================================================
+int pio_ln_fold_enable(int on) { return ln_fold_enable(on); }
+
 size_t pio_self_attention_workspace_bytes(const pio_self_attention_t *sa, int32_t B, int32_t N) {
     if (!sa) return 0;
     SelfPlan p;
@@ -533,11 +631,12 @@ int pio_encoder_fwd(const pio_cross_attention_t *cross, const pio_self_attention
                                     cp, s));
     }
     const pio_tensor3_t z = {out, (int64_t)N * D, D, B, N, D};
+    FoldCarry carry;  // LayerNorm fold: the row statistics of z travel from one block's fc2 to the next block's q|k|v
     for (int blk = 0; blk < num_blocks; ++blk) {  // perceiver.py:104-106: weights shared across blocks
         for (int l = 0; l < L; ++l) {
             SelfPlan sp;
             sp.carve(workspace, layers[l], B, N);
-            PIO_TRY(self_attention_run(layers[l], z, nullptr, nullptr, nullptr, nullptr, out, nullptr, sp, s));
+            PIO_TRY(self_attention_run(layers[l], z, nullptr, nullptr, nullptr, nullptr, out, nullptr, sp, s, &carry));
         }
     }
     return PIO_OK;

@@ -225,6 +225,56 @@ __global__ __launch_bounds__(256) void layernorm_cast_reg_kernel(const float *__
     }
 }
 
+// LayerNorm fold, first layer of a stack: y = cast(x) (NOT normalised) and, per row and 128-column block, the (sum,
+// sum of squares) that the fold's consumer GEMM turns into mean / rstd.  C == 1024, contiguous rows; one wave per row:
+// float4 j of lane l covers columns 256 j + 4 l, i.e. block 2 j + (l >> 5).
+template <int DT>
+__global__ __launch_bounds__(256) void rowstats_cast_kernel(const float *__restrict__ x, int64_t rows,
+                                                            typename Op<DT>::T *__restrict__ y,
+                                                            float *__restrict__ part) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float *xr = x + row * 1024;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int i = (j * 64 + lane) * 4;
+        const f32x4 v = *(const f32x4 *)(xr + i);
+        float sm = (v[0] + v[1]) + (v[2] + v[3]);
+        float sq = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) {
+            sm += __shfl_xor(sm, o, 64);
+            sq += __shfl_xor(sq, o, 64);
+        }
+        if ((lane & 31) == 0) {
+            float *dst = part + (row * 8 + 2 * j + (lane >> 5)) * 2;
+            dst[0] = sm;
+            dst[1] = sq;
+        }
+        typename Op<DT>::V4 o4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o4[e] = Op<DT>::from_f32(v[e]);
+        *(typename Op<DT>::V4 *)(y + row * 1024 + i) = o4;
+    }
+}
+
+int rowstats_cast_launch(const float *x, int64_t rows, void *y16, float *part, int dtype, hipStream_t s) {
+    if (!x || !y16 || !part || rows <= 0) return PIO_E_ARG;
+    if (((uintptr_t)x & 15) || ((uintptr_t)y16 & 7) || ((uintptr_t)part & 7)) return PIO_E_ALIGN;
+    ProfScope prof(PROF_LAYERNORM, 0.0, (double)rows * 1024 * 6.0, s);
+    const unsigned blocks = (unsigned)((rows + 3) / 4);
+    if (dtype == PIO_DT_F16)
+        hipLaunchKernelGGL((rowstats_cast_kernel<PIO_DT_F16>), dim3(blocks), dim3(256), 0, s, x, rows,
+                           (Op<PIO_DT_F16>::T *)y16, part);
+    else if (dtype == PIO_DT_BF16)
+        hipLaunchKernelGGL((rowstats_cast_kernel<PIO_DT_BF16>), dim3(blocks), dim3(256), 0, s, x, rows,
+                           (Op<PIO_DT_BF16>::T *)y16, part);
+    else
+        return PIO_E_ARG;
+    return launch_status();
+}
+
 // The same with 8-byte (float2) accesses for even channel counts whose rows are only 8-byte aligned -- the 322-wide
 // encoder input array [B, 3136, 322]: 129 MB at B = 32, the largest single read of the model.
 template <int DT, bool NORM>

@@ -90,6 +90,11 @@ int gemm_nt_launch(const pio_gemm_t &g, hipStream_t s);
 int gemm_kernel_override(int which);  // 0 auto, 128, 256, 1 = streaming; returns the previous choice
 int layernorm_cast_launch(const pio_tensor3_t &x, const pio_layernorm_t *ln, void *y, void *y_lo, int c_pad,
                           int dtype, hipStream_t s);
+// LayerNorm fold: 16-bit cast of contiguous 1024-channel rows + their per-128-column (sum, sum of squares), the form
+// the fold's consumer GEMM reads (first layer of a stack: later layers get both from the producing GEMM)
+int rowstats_cast_launch(const float *x, int64_t rows, void *y16, float *part, int dtype, hipStream_t s);
+int ln_fold_enable(int on);   // returns the previous setting
+bool ln_fold_enabled();
 int softmax_rows_launch(const float *S, int64_t lds, void *P, void *P_lo, int64_t ldp, int B, int H, int Tq, int Tk,
                         float scale, const uint8_t *kv_mask, const uint8_t *q_mask, const uint8_t *full_mask,
                         const float *bias, int dtype, float *probs_out, hipStream_t s);

@@ -270,7 +270,35 @@ class SelfAttention(_HipModule):
         a = self.attention._desc()
         m = self.mlp._desc()
         d = L.SelfAttention(R.layernorm_desc(self.layer_norm1, keep), R.layernorm_desc(self.layer_norm2, keep), a, m)
+        self._build_ln_fold(d, a, keep)
         return d, keep + [self.attention._pio_cache, self.mlp._pio_cache]
+
+    def _build_ln_fold(self, d, a, keep):
+        """LayerNorm folded into the consuming GEMMs (pio_ln_fold_t): LN(x) W^T + b = rstd (x W'^T - mean c) + b' with
+        W' = W * gamma, c = rowsum(W' as packed), b' = W beta + b (reference :281-292 computes LN then Linear).
+        Offered for 1024-channel blocks under the single-sweep policies; the library decides per call."""
+        dtype, wlevel, split = R.policy_dtype()
+        att, mlp = self.attention, self.mlp
+        if (wlevel != 0 or split or self._in_channels != 1024 or not a.qkv.w_hi
+                or mlp.fc1.in_features != 1024 or att.proj_q.in_features != 1024):
+            return
+        with torch.no_grad():
+            g1, b1 = self.layer_norm1.weight.float(), self.layer_norm1.bias.float()
+            g2, b2 = self.layer_norm2.weight.float(), self.layer_norm2.bias.float()
+
+            def folded(lin, g, b):
+                w = lin.weight.float()
+                bias = lin.bias.float() if lin.bias is not None else torch.zeros(w.shape[0], device=w.device)
+                return (w * g[None, :]).contiguous(), (w @ b + bias).contiguous()
+
+            H = att._num_heads
+            qkv = R.PackedStack([folded(att.proj_q, g1, b1), folded(att.proj_k, g1, b1), folded(att.proj_v, g1, b1)],
+                                H, dtype, False)
+            fc1 = R.PackedLinear(*folded(mlp.fc1, g2, b2), 1, 1, dtype, False)
+            qkv_c = qkv.hi.float().sum(1).contiguous()
+            fc1_c = fc1.hi.float().sum(1).contiguous()
+        d.fold = L.LnFold(qkv.desc, qkv_c.data_ptr(), fc1.desc, fc1_c.data_ptr())
+        keep.extend([qkv, fc1, qkv_c, fc1_c])
 
     def _params(self):
         return self.attention._params() + self.mlp._params() + (self.layer_norm1.weight, self.layer_norm1.bias,

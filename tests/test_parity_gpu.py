@@ -683,3 +683,88 @@ def test_gemm_layernorm_fold(dev, M, N2, act, dt):
         ref2 = torch.nn.functional.gelu(ref2)
     err2 = ((got - ref2).abs().max() / ref2.abs().max()).item()
     assert err2 <= (1e-3 if dt == "f16" else 8e-3), f"folded LayerNorm GEMM vs same-rounding reference: {err2:.3e}"
+
+
+def _sa_reference64(m, x):
+    """SelfAttention.forward of the reference (transformer_primitives.py:281-292) in torch float64."""
+    F = torch.nn.functional
+    d = lambda t: t.detach().double()  # noqa: E731
+    xd = x.double()
+    B, N, D = xd.shape
+    H = m.attention._num_heads
+    a = m.attention
+    n1 = F.layer_norm(xd, (D,), d(m.layer_norm1.weight), d(m.layer_norm1.bias), m.layer_norm1.eps)
+    q = (n1 @ d(a.proj_q.weight).T + d(a.proj_q.bias)).reshape(B, N, H, -1).permute(0, 2, 1, 3)
+    k = (n1 @ d(a.proj_k.weight).T + d(a.proj_k.bias)).reshape(B, N, H, -1).permute(0, 2, 1, 3)
+    v = (n1 @ d(a.proj_v.weight).T + d(a.proj_v.bias)).reshape(B, N, H, -1).permute(0, 2, 1, 3)
+    p = torch.softmax(q @ k.transpose(-1, -2) / q.shape[-1] ** 0.5, -1)
+    o = (p @ v).permute(0, 2, 1, 3).reshape(B, N, -1)
+    x1 = xd + o @ d(a.final.weight).T + d(a.final.bias)
+    n2 = F.layer_norm(x1, (D,), d(m.layer_norm2.weight), d(m.layer_norm2.bias), m.layer_norm2.eps)
+    h = F.gelu(n2 @ d(m.mlp.fc1.weight).T + d(m.mlp.fc1.bias))
+    return x1 + h @ d(m.mlp.fc2.weight).T + d(m.mlp.fc2.bias)
+
+
+@pytest.mark.parametrize("policy", ["fp16", "bf16"])
+def test_self_attention_layernorm_fold(dev, policy):
+    """A 1024-channel SelfAttention block with the LayerNorms folded into the GEMMs around them (pio_ln_fold_t)
+    against torch float64 of the reference's forward, and against the same block with the fold switched off."""
+    import perceiverio_pytorch_amd as P
+    from perceiverio_pytorch_amd import _lib as L
+    from perceiverio_pytorch_amd.transformer_primitives import SelfAttention
+    lib = L.lib()
+    _policy(policy)
+    torch.manual_seed(5)
+    m = SelfAttention(1024, widening_factor=1, num_heads=8)
+    with torch.no_grad():
+        for ln in (m.layer_norm1, m.layer_norm2):
+            ln.weight.add_(0.1 * torch.randn(1024))
+            ln.bias.add_(0.1 * torch.randn(1024))
+        for lin in (m.attention.proj_q, m.attention.proj_k, m.attention.proj_v, m.attention.final, m.mlp.fc1, m.mlp.fc2):
+            lin.bias.add_(0.05 * torch.randn(lin.bias.shape))
+    m = m.to(dev).eval()
+    x = (torch.randn(4, 512, 1024) * 1.5 + 0.2).to(dev)
+    ref = _sa_reference64(m, x)
+    prev = lib.pio_ln_fold_enable(1)
+    try:
+        with torch.inference_mode():
+            y_fold = m(x).double()
+            lib.pio_ln_fold_enable(0)
+            y_plain = m(x).double()
+    finally:
+        lib.pio_ln_fold_enable(prev)
+    scale = ref.abs().max()
+    e_fold = ((y_fold - ref).abs().max() / scale).item()
+    e_plain = ((y_plain - ref).abs().max() / scale).item()
+    assert not torch.equal(y_fold, y_plain), "the fold did not run (identical results)"
+    tol = 2e-3 if policy == "fp16" else 1.5e-2
+    assert e_fold <= tol, f"folded block {policy}: {e_fold:.3e} (unfolded {e_plain:.3e})"
+    assert e_fold <= 1.5 * e_plain + 2e-4, f"folded block {policy}: {e_fold:.3e} vs unfolded {e_plain:.3e}"
+
+
+def test_model_layernorm_fold_b4(dev):
+    """Full ClassificationPerceiver at B = 4 (2048 latent rows: the fold is taken, with the row statistics carried from
+    block to block), policy fp16: folded vs unfolded logits against the fp16x3 (float32-grade) run of the same model."""
+    import os as _os
+    import sys as _sys
+    _sys.path.insert(0, _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), ".."))
+    import bench as Bn
+    from perceiverio_pytorch_amd import _lib as L
+    lib = L.lib()
+    model, _, _ = Bn.build_model(dev, "fp16")
+    x = torch.randn(4, 3, 224, 224, generator=torch.Generator().manual_seed(11)).to(dev)
+    prev = lib.pio_ln_fold_enable(1)
+    try:
+        with torch.inference_mode():
+            y_fold = model(x).double()
+            lib.pio_ln_fold_enable(0)
+            y_plain = model(x).double()
+            model.precision_policy = "fp16x3"
+            y_ref = model(x).double()
+    finally:
+        lib.pio_ln_fold_enable(prev)
+    rel = lambda a, b: ((a - b).norm() / b.norm()).item()  # noqa: E731
+    e_fold, e_plain = rel(y_fold, y_ref), rel(y_plain, y_ref)
+    assert not torch.equal(y_fold, y_plain), "the fold did not run (identical results)"
+    assert e_fold <= 1e-3, f"folded model relL2 {e_fold:.3e} (unfolded {e_plain:.3e})"
+    assert e_fold <= 1.5 * e_plain + 1e-4, f"folded model relL2 {e_fold:.3e} vs unfolded {e_plain:.3e}"
