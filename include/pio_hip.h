@@ -214,6 +214,11 @@ typedef struct pio_gemm_t {
     const float *ln_part;
     const float *ln_c;
     float ln_eps;
+    /* The residual stream as a 16-bit pair (producer only): X16_lo receives result - float(X16) (same layout as X16),
+     * and the residual may be given as R16_hi + R16_lo (row stride ld16, instead of the fp32 R).  With X16 and X16_lo
+     * both set, C may be NULL: the fp32 result is then not written at all. */
+    void *X16_lo;
+    const void *R16_hi, *R16_lo;
 } pio_gemm_t;
 int pio_gemm_nt(const pio_gemm_t *g, void *stream);
 

@@ -77,7 +77,8 @@ class Gemm(C.Structure):
                 ("r_rows_per_batch", C.c_int32), ("out_f32", C.c_int32), ("n_store", C.c_int32),
                 ("dtype", C.c_int32),
                 ("X16", C.c_void_p), ("ld16", C.c_int64), ("row_part", C.c_void_p), ("ln_part", C.c_void_p),
-                ("ln_c", C.c_void_p), ("ln_eps", C.c_float)]
+                ("ln_c", C.c_void_p), ("ln_eps", C.c_float),
+                ("X16_lo", C.c_void_p), ("R16_hi", C.c_void_p), ("R16_lo", C.c_void_p)]
 
 
 # name -> (restype, argtypes); must list EVERY function declared in include/pio_hip.h

@@ -66,6 +66,10 @@ struct LnFold {
     void *out16 = nullptr;
     int64_t ld16 = 0;
     float *out_part = nullptr;
+    // ... and the residual stream as a 16-bit pair: lo half of the result, residual given as (hi, lo); with both the
+    // fp32 output pointer of the GEMM may be null
+    void *out16_lo = nullptr;
+    const void *res16_hi = nullptr, *res16_lo = nullptr;
 };
 
 // y[rows, n] = x16[rows, lin.k] * W^T (+bias) (act) (+R); a 16-bit output has ldc = lin.n (padded).
@@ -83,6 +87,9 @@ static int linear_fwd(const pio_linear_t &lin_plain, int dtype, Pair x, int64_t 
         g.X16 = fold->out16;
         g.ld16 = fold->ld16;
         g.row_part = fold->out_part;
+        g.X16_lo = fold->out16_lo;
+        g.R16_hi = fold->res16_hi;
+        g.R16_lo = fold->res16_lo;
     }
     g.A = x.hi;
     g.A_lo = x.lo;
@@ -101,7 +108,7 @@ static int linear_fwd(const pio_linear_t &lin_plain, int dtype, Pair x, int64_t 
     g.act = act;
     g.out_f32 = out_f32 ? 1 : 0;
     g.n_store = g.N;
-    if (res && res->ptr) {
+    if (res && res->ptr && !(fold && fold->res16_hi)) {
         g.R = res->ptr;
         g.ldr = res->ld;
         g.r_stride_b = res->stride_b;
@@ -337,7 +344,7 @@ struct SelfPlan {
     AttnScratch core;
     // LayerNorm fold (pio_ln_fold_t): 16-bit copy of x1 and the per-row partial sums of x (A) and x1 (B); the 16-bit
     // copy of x lives in x16
-    void *x16b = nullptr;
+    void *x16b = nullptr, *lo_a = nullptr, *lo_b = nullptr;  // lo_*: x - x16 / x1 - x16b (the stream as a 16-bit pair)
     float *part_a = nullptr, *part_b = nullptr;
     size_t carve(void *base, const pio_self_attention_t &sa, int B, int N) {
         Carver c(base);
@@ -349,6 +356,8 @@ struct SelfPlan {
         core.carve(c, sa.attn, B, B, N, N);
         if (sa.fold.qkv.w_hi && sa.fold.fc1.w_hi) {
             x16b = c.take((size_t)rows * cmax * 2);
+            lo_a = c.take((size_t)rows * cmax * 2);
+            lo_b = c.take((size_t)rows * cmax * 2);
             part_a = (float *)c.take((size_t)rows * 8 * 2 * 4);
             part_b = (float *)c.take((size_t)rows * 8 * 2 * 4);
         }
@@ -375,14 +384,16 @@ bool ln_fold_enabled() { return ln_fold_choice() != 0; }
 // Carried from one SelfAttention block to the next inside a stack: the 16-bit copy and the partial sums of the block's
 // INPUT, left in the plan's (x16, part_a) buffers by the previous block's fc2 GEMM.
 struct FoldCarry {
-    const void *x = nullptr;  // the fp32 tensor they describe
+    const void *x = nullptr;  // the fp32 tensor they describe (its CONTENT is stale unless f32_valid)
     const void *x16 = nullptr;
     const float *part = nullptr;
+    bool f32_valid = true;
 };
 
 static int self_attention_run(const pio_self_attention_t &sa, const pio_tensor3_t &x, const uint8_t *kv_mask,
                               const uint8_t *q_mask, const uint8_t *full_mask, const float *attention_bias,
-                              float *out, float *probs_out, SelfPlan &p, hipStream_t s, FoldCarry *carry = nullptr) {
+                              float *out, float *probs_out, SelfPlan &p, hipStream_t s, FoldCarry *carry = nullptr,
+                              bool need_f32_out = true) {
     const int B = x.B, N = x.T;
     const int64_t rows = (int64_t)B * N;
     if (x.C != sa.attn.q_in || sa.attn.k_in != x.C || sa.attn.v_in != x.C || sa.attn.out != x.C ||
@@ -399,29 +410,40 @@ static int self_attention_run(const pio_self_attention_t &sa, const pio_tensor3_
                       !probs_out && (((uintptr_t)x.data) & 15) == 0;
     if (fold) {
         // x16 / part_a: the block input (from the previous block's fc2, or computed here for the first block)
-        if (!(carry && carry->x == x.data && carry->x16 == p.x16.hi && carry->part == p.part_a))
-            PIO_TRY(rowstats_cast_launch(x.data, rows, p.x16.hi, p.part_a, sa.attn.dtype, s));
+        // Inside the fold the residual stream is the 16-bit pair (x16, lo): 22 mantissa bits, and 64 MB less traffic
+        // per residual GEMM than fp32 + copy.  The fp32 form is read here once (first block) and written when the
+        // caller needs it (last block).
+        if (!(carry && carry->x == x.data && carry->x16 == p.x16.hi && carry->part == p.part_a)) {
+            if (carry && !carry->f32_valid) return PIO_E_ARG;  // (the stack decides the fold for all its blocks)
+            PIO_TRY(rowstats_cast_launch(x.data, rows, p.x16.hi, p.lo_a, p.part_a, sa.attn.dtype, s));
+        }
         const Pair xa = {p.x16.hi, nullptr};
         LnFold f_qkv, f_out, f_fc1, f_fc2;
         f_qkv.in_part = p.part_a; f_qkv.w = &sa.fold.qkv; f_qkv.c = sa.fold.qkv_c; f_qkv.eps = sa.ln1.eps;
         f_out.out16 = p.x16b; f_out.ld16 = x.C; f_out.out_part = p.part_b;
+        f_out.out16_lo = p.lo_b; f_out.res16_hi = p.x16.hi; f_out.res16_lo = p.lo_a;
         f_fc1.in_part = p.part_b; f_fc1.w = &sa.fold.fc1; f_fc1.c = sa.fold.fc1_c; f_fc1.eps = sa.ln2.eps;
         f_fc2.out16 = p.x16.hi; f_fc2.ld16 = x.C; f_fc2.out_part = p.part_a;
+        f_fc2.out16_lo = p.lo_a; f_fc2.res16_hi = p.x16b; f_fc2.res16_lo = p.lo_b;
         const Residual rx = residual_of(x);
-        PIO_TRY(attention_core(sa.attn, xa, false, xa, xa, B, N, N, nullptr, nullptr, nullptr, nullptr, &rx, p.x1,
-                               nullptr, p.core, s, &f_qkv, &f_out));
+        PIO_TRY(attention_core(sa.attn, xa, false, xa, xa, B, N, N, nullptr, nullptr, nullptr, nullptr, &rx, nullptr,
+                               nullptr, p.core, s, &f_qkv, &f_out));  // (x1 exists as the pair (x16b, lo_b) only)
         pio_tensor3_t t1 = {p.x1, (int64_t)N * x.C, x.C, B, N, x.C};
         const Pair xm = {p.x16b, nullptr};
         const Residual r1 = residual_of(t1);
-        PIO_TRY(mlp_core(sa.mlp, xm, rows, p.h16, &r1, out, s, &f_fc1, &f_fc2));
+        PIO_TRY(mlp_core(sa.mlp, xm, rows, p.h16, &r1, need_f32_out ? out : nullptr, s, &f_fc1, &f_fc2));
         if (carry) {
             carry->x = out;
             carry->x16 = p.x16.hi;
             carry->part = p.part_a;
+            carry->f32_valid = need_f32_out;
         }
         return PIO_OK;
     }
-    if (carry) *carry = FoldCarry();
+    if (carry) {
+        if (!carry->f32_valid) return PIO_E_ARG;  // (the stack decides the fold for all its blocks)
+        *carry = FoldCarry();
+    }
     // LN1 -> attention -> + x     (transformer_primitives.py:281-290)
     const Pair xa = pair_if(p.x16, sa.attn.act_split);
     PIO_TRY(cast_pair(x, &sa.ln1, xa, pad8(x.C), sa.attn.dtype, s));
@@ -636,7 +658,9 @@ int pio_encoder_fwd(const pio_cross_attention_t *cross, const pio_self_attention
         for (int l = 0; l < L; ++l) {
             SelfPlan sp;
             sp.carve(workspace, layers[l], B, N);
-            PIO_TRY(self_attention_run(layers[l], z, nullptr, nullptr, nullptr, nullptr, out, nullptr, sp, s, &carry));
+            const bool last = blk == num_blocks - 1 && l == L - 1;
+            PIO_TRY(self_attention_run(layers[l], z, nullptr, nullptr, nullptr, nullptr, out, nullptr, sp, s, &carry,
+                                       last));
         }
     }
     return PIO_OK;

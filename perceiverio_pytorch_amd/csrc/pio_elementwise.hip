@@ -225,12 +225,13 @@ __global__ __launch_bounds__(256) void layernorm_cast_reg_kernel(const float *__
     }
 }
 
-// LayerNorm fold, first layer of a stack: y = cast(x) (NOT normalised) and, per row and 128-column block, the (sum,
+// LayerNorm fold, first layer of a stack: y = cast(x) (NOT normalised; optionally y_lo = x - y) and, per row and 128-column block, the (sum,
 // sum of squares) that the fold's consumer GEMM turns into mean / rstd.  C == 1024, contiguous rows; one wave per row:
 // float4 j of lane l covers columns 256 j + 4 l, i.e. block 2 j + (l >> 5).
 template <int DT>
 __global__ __launch_bounds__(256) void rowstats_cast_kernel(const float *__restrict__ x, int64_t rows,
                                                             typename Op<DT>::T *__restrict__ y,
+                                                            typename Op<DT>::T *__restrict__ y_lo,
                                                             float *__restrict__ part) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -252,24 +253,30 @@ __global__ __launch_bounds__(256) void rowstats_cast_kernel(const float *__restr
             dst[0] = sm;
             dst[1] = sq;
         }
-        typename Op<DT>::V4 o4;
+        typename Op<DT>::V4 o4, l4;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o4[e] = Op<DT>::from_f32(v[e]);
+        for (int e = 0; e < 4; ++e) {
+            o4[e] = Op<DT>::from_f32(v[e]);
+            l4[e] = Op<DT>::from_f32(v[e] - Op<DT>::to_f32(o4[e]));
+        }
         *(typename Op<DT>::V4 *)(y + row * 1024 + i) = o4;
+        if (y_lo) *(typename Op<DT>::V4 *)(y_lo + row * 1024 + i) = l4;
     }
 }
 
-int rowstats_cast_launch(const float *x, int64_t rows, void *y16, float *part, int dtype, hipStream_t s) {
+int rowstats_cast_launch(const float *x, int64_t rows, void *y16, void *y16_lo, float *part, int dtype,
+                         hipStream_t s) {
     if (!x || !y16 || !part || rows <= 0) return PIO_E_ARG;
     if (((uintptr_t)x & 15) || ((uintptr_t)y16 & 7) || ((uintptr_t)part & 7)) return PIO_E_ALIGN;
-    ProfScope prof(PROF_LAYERNORM, 0.0, (double)rows * 1024 * 6.0, s);
+    if ((uintptr_t)y16_lo & 7) return PIO_E_ALIGN;
+    ProfScope prof(PROF_LAYERNORM, 0.0, (double)rows * 1024 * (y16_lo ? 8.0 : 6.0), s);
     const unsigned blocks = (unsigned)((rows + 3) / 4);
     if (dtype == PIO_DT_F16)
         hipLaunchKernelGGL((rowstats_cast_kernel<PIO_DT_F16>), dim3(blocks), dim3(256), 0, s, x, rows,
-                           (Op<PIO_DT_F16>::T *)y16, part);
+                           (Op<PIO_DT_F16>::T *)y16, (Op<PIO_DT_F16>::T *)y16_lo, part);
     else if (dtype == PIO_DT_BF16)
         hipLaunchKernelGGL((rowstats_cast_kernel<PIO_DT_BF16>), dim3(blocks), dim3(256), 0, s, x, rows,
-                           (Op<PIO_DT_BF16>::T *)y16, part);
+                           (Op<PIO_DT_BF16>::T *)y16, (Op<PIO_DT_BF16>::T *)y16_lo, part);
     else
         return PIO_E_ARG;
     return launch_status();

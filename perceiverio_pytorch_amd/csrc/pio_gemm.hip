@@ -247,7 +247,8 @@ int gemm_kernel_override(int which) {
 }
 
 int gemm_nt_launch(const pio_gemm_t &g, hipStream_t s) {
-    if (!g.A || !g.B || !g.C) return PIO_E_ARG;
+    if (!g.A || !g.B) return PIO_E_ARG;
+    if (!g.C && !(g.X16 && g.X16_lo && g.out_f32)) return PIO_E_ARG;  // (fp32 C is optional beside a 16-bit pair)
     if (g.M <= 0 || g.N <= 0 || g.K <= 0 || g.batch <= 0 || g.nh <= 0) return PIO_E_SHAPE;
     if (g.K % 8) return PIO_E_SHAPE;
     if (g.batch % g.nh) return PIO_E_SHAPE;
@@ -282,8 +283,9 @@ int gemm_nt_launch(const pio_gemm_t &g, hipStream_t s) {
     p.out_f32 = g.out_f32;
     p.X16 = g.X16; p.ld16 = g.ld16; p.row_part = g.row_part;
     p.ln_part = g.ln_part; p.ln_c = g.ln_c; p.ln_eps = g.ln_eps;
+    p.X16_lo = g.X16_lo; p.R16_hi = g.R16_hi; p.R16_lo = g.R16_lo;
     p.n_store = g.n_store > g.N ? g.n_store : g.N;
-    if (p.n_store > g.ldc) return PIO_E_SHAPE;
+    if (g.C && p.n_store > g.ldc) return PIO_E_SHAPE;
     p.tiles_n = (p.n_store + BN - 1) / BN;
     const int tiles_m = (g.M + BM - 1) / BM;
     const size_t esz = g.out_f32 ? 4 : 2;
@@ -321,7 +323,7 @@ int gemm_nt_launch(const pio_gemm_t &g, hipStream_t s) {
                         (int64_t)tm256 * tn256 >= 256 && (!p.R || wide_residual());
             if (forced == 2) wide = true;
             if (forced == 1 || forced == 128 || forced == 256) wide = false;
-            const bool fold = p.X16 || p.row_part || p.ln_part || p.ln_c;  // only this kernel implements the fold
+            const bool fold = p.X16 || p.row_part || p.ln_part || p.ln_c || p.X16_lo || p.R16_hi || p.R16_lo;
             if (fold) {
                 if (!gemm_wide_ok(p, g.batch)) return PIO_E_SHAPE;
                 wide = true;

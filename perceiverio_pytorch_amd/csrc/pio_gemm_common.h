@@ -30,6 +30,8 @@ struct GemmParams {
     float *row_part;
     const float *ln_part, *ln_c;
     float ln_eps;
+    void *X16_lo;
+    const void *R16_hi, *R16_lo;
 };
 
 

@@ -104,11 +104,12 @@ __device__ __forceinline__ void mfma_first(f32x4 &c, typename Op<DT>::V8 a, type
     else asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(c) : "v"(a), "v"(b));
 }
 
-// OUT: 0 = 16-bit C, 2 = fp32 C (optionally + residual R: HAS_R).
+// OUT: 0 = 16-bit C, 2 = fp32 C; RES: 0 = no residual, 1 = fp32 residual R, 2 = residual as a 16-bit pair
+// R16_hi + R16_lo (LNF == 1 only; the result then leaves as the pair X16 / X16_lo, and as fp32 only if C is given).
 // LNF, the LayerNorm fold (pio_gemm_t): 1 = producer (OUT == 2): also stores a 16-bit copy of the result and per-row
 // partial (sum, sum of squares) per 128-column block; 2 = consumer (OUT == 0, K == 1024): the result is
 // rstd_m * acc - rstd_m * mean_m * c[n] + bias[n], with mean / rstd of row m of A from the producer's partial sums.
-template <int DT, int ACT, int OUT, bool HAS_R, int LNF>
+template <int DT, int ACT, int OUT, int RES, int LNF>
 __global__ __launch_bounds__(256) void gemm_nt_wide(const GemmParams p, int tiles_m, int tiles_n) {
     typedef typename Op<DT>::T T;
     typedef typename Op<DT>::V8 V8;
@@ -385,27 +386,40 @@ __global__ __launch_bounds__(256) void gemm_nt_wide(const GemmParams p, int tile
                 b1[pp] = *(const f32x4 *)(bstash + pp * 32 + fq * 8 + 4);
             }
             const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-            f32x4 rb[2][8];
+            f32x4 rb[2][8];   // RES == 1: residual of a row block as fp32; RES == 2: rp = (hi, lo) 16-bit pairs
+            V8 rp[2][8];
+            const V8 zero8 = {};
             auto r_load = [&](int set, int mi) {
                 const int m = o_m + mi * 16;
 #pragma unroll
                 for (int pp = 0; pp < 4; ++pp) {
                     const int n = o_n + pp * 32;
-                    if (interior || (m < p.M && n < p.N)) {
-                        const float *src = p.R + (int64_t)m * p.ldr + n;
-                        rb[set][2 * pp] = *(const f32x4 *)src;
-                        rb[set][2 * pp + 1] = *(const f32x4 *)(src + 4);
+                    const bool in = interior || (m < p.M && n < p.N);
+                    if constexpr (RES == 1) {
+                        if (in) {
+                            const float *src = p.R + (int64_t)m * p.ldr + n;
+                            rb[set][2 * pp] = *(const f32x4 *)src;
+                            rb[set][2 * pp + 1] = *(const f32x4 *)(src + 4);
+                        } else {
+                            rb[set][2 * pp] = zero4;
+                            rb[set][2 * pp + 1] = zero4;
+                        }
                     } else {
-                        rb[set][2 * pp] = zero4;
-                        rb[set][2 * pp + 1] = zero4;
+                        if (in) {
+                            rp[set][2 * pp] = *(const V8 *)((const T *)p.R16_hi + (int64_t)m * p.ld16 + n);
+                            rp[set][2 * pp + 1] = *(const V8 *)((const T *)p.R16_lo + (int64_t)m * p.ld16 + n);
+                        } else {
+                            rp[set][2 * pp] = zero8;
+                            rp[set][2 * pp + 1] = zero8;
+                        }
                     }
                 }
             };
-            if constexpr (HAS_R) r_load(0, 0);
+            if constexpr (RES != 0) r_load(0, 0);
 #pragma unroll
             for (int mi = 0; mi < 8; ++mi) {
                 const int m = o_m + mi * 16;
-                if constexpr (HAS_R) {
+                if constexpr (RES != 0) {
                     if (mi < 7) r_load((mi + 1) & 1, mi + 1);
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -419,18 +433,27 @@ __global__ __launch_bounds__(256) void gemm_nt_wide(const GemmParams p, int tile
                         x0[r] = acc_read(acc[mi][2 * pp][r]) * p.alpha + b0[pp][r];
                         x1[r] = acc_read(acc[mi][2 * pp + 1][r]) * p.alpha + b1[pp][r];
                     }
-                    if constexpr (HAS_R) {
+                    if constexpr (RES == 1) {
                         x0 += rb[mi & 1][2 * pp];
                         x1 += rb[mi & 1][2 * pp + 1];
+                    } else if constexpr (RES == 2) {
+                        const V8 hh = rp[mi & 1][2 * pp], ll = rp[mi & 1][2 * pp + 1];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            x0[r] += Op<DT>::to_f32(hh[r]) + Op<DT>::to_f32(ll[r]);
+                            x1[r] += Op<DT>::to_f32(hh[4 + r]) + Op<DT>::to_f32(ll[4 + r]);
+                        }
                     }
                     if (!interior && n >= p.N) {
                         x0 = zero4;  // columns [N, n_store): zeros
                         x1 = zero4;
                     }
                     const bool ok = interior || (m < p.M && n < p.n_store);
-                    char *dst = ok ? (char *)(cf + (int64_t)m * p.ldc + n) : sink;
-                    *(f32x4 *)dst = x0;
-                    *(f32x4 *)(ok ? dst + 16 : dst) = x1;
+                    if (LNF != 1 || cf) {  // (beside a 16-bit pair the fp32 result is optional)
+                        char *dst = ok ? (char *)(cf + (int64_t)m * p.ldc + n) : sink;
+                        *(f32x4 *)dst = x0;
+                        *(f32x4 *)(ok ? dst + 16 : dst) = x1;
+                    }
                     if constexpr (LNF == 1) {
                         V8 h;
 #pragma unroll
@@ -441,6 +464,15 @@ __global__ __launch_bounds__(256) void gemm_nt_wide(const GemmParams p, int tile
                             h[4 + r] = Op<DT>::from_f32(x1[r]);
                         }
                         *(V8 *)(ok ? (char *)((T *)p.X16 + (int64_t)m * p.ld16 + n) : sink) = h;
+                        if (p.X16_lo) {
+                            V8 l;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                l[r] = Op<DT>::from_f32(x0[r] - Op<DT>::to_f32(h[r]));
+                                l[4 + r] = Op<DT>::from_f32(x1[r] - Op<DT>::to_f32(h[4 + r]));
+                            }
+                            *(V8 *)(ok ? (char *)((T *)p.X16_lo + (int64_t)m * p.ld16 + n) : sink) = l;
+                        }
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -592,12 +624,16 @@ bool gemm_wide_ok(const GemmParams &p, int batch) {
     if (batch != 1 || p.npass != 1) return false;
     if (p.K < 4 * W_BK || (p.K % (2 * W_BK))) return false;
     if (p.C_lo || (p.act != 0 && p.act != 1)) return false;
-    if (p.out_f32 && (p.act != 0 || (p.ldc & 3))) return false;
+    if (p.out_f32 && (p.act != 0 || (p.C && (p.ldc & 3)))) return false;
     if (p.R && (!p.out_f32 || !p.r_vec || p.r_rows != 0 || (p.ldr & 3))) return false;
-    if (p.X16 || p.row_part) {  // LayerNorm-fold producer
-        if (!p.X16 || !p.row_part || !p.out_f32 || !p.R || (p.N & 127) || (p.ld16 & 7) || ((uintptr_t)p.X16 & 15) ||
+    if (p.X16 || p.row_part || p.X16_lo || p.R16_hi || p.R16_lo) {  // LayerNorm-fold producer
+        const bool pair_r = p.R16_hi || p.R16_lo;
+        if (!p.X16 || !p.row_part || !p.out_f32 || (p.N & 127) || (p.ld16 & 7) || ((uintptr_t)p.X16 & 15) ||
             ((uintptr_t)p.row_part & 7) || p.ln_part || p.ln_c)
             return false;
+        if (pair_r ? (!p.R16_hi || !p.R16_lo || p.R || ((uintptr_t)p.R16_hi & 15) || ((uintptr_t)p.R16_lo & 15)) : !p.R)
+            return false;
+        if (((uintptr_t)p.X16_lo & 15) || (!p.C && !p.X16_lo)) return false;
     }
     if (p.ln_part || p.ln_c) {  // LayerNorm-fold consumer
         if (!p.ln_part || !p.ln_c || p.out_f32 || p.K != 1024 || p.alpha != 1.0f || ((uintptr_t)p.ln_c & 15) ||
@@ -605,7 +641,7 @@ bool gemm_wide_ok(const GemmParams &p, int batch) {
             return false;
     }
     if (p.bias_mode > 1 || (p.bias_mode == 1 && !p.bias_vec)) return false;
-    if ((p.N & 7) || (p.n_store & 7) || (p.ldc & 7) || ((uintptr_t)p.C & 15)) return false;
+    if ((p.N & 7) || (p.n_store & 7) || (p.C && ((p.ldc & 7) || ((uintptr_t)p.C & 15)))) return false;
     if ((p.lda & 7) || (p.ldb & 7) || ((uintptr_t)p.A & 15) || ((uintptr_t)p.B & 15)) return false;
     if (((int64_t)p.M * p.lda + p.K) * 2 >= (1ll << 32) || ((int64_t)p.N * p.ldb + p.K) * 2 >= (1ll << 32)) return false;
     return true;
@@ -619,13 +655,14 @@ void gemm_wide_launch(const GemmParams &p, int dtype, hipStream_t s) {
     hipLaunchKernelGGL((gemm_nt_wide<DTV, ACT, OUT, R, LNF>), grid, block, 0, s, p, tiles_m, tiles_n)
 #define PIO_WS(DTV)                                                  \
     do {                                                             \
-        if (p.row_part) PIO_WK(DTV, 0, 2, true, 1);                  \
-        else if (p.out_f32 && p.R) PIO_WK(DTV, 0, 2, true, 0);       \
-        else if (p.out_f32) PIO_WK(DTV, 0, 2, false, 0);             \
-        else if (p.ln_part && p.act == 1) PIO_WK(DTV, 1, 0, false, 2); \
-        else if (p.ln_part) PIO_WK(DTV, 0, 0, false, 2);             \
-        else if (p.act == 1) PIO_WK(DTV, 1, 0, false, 0);            \
-        else PIO_WK(DTV, 0, 0, false, 0);                            \
+        if (p.row_part && p.R16_hi) PIO_WK(DTV, 0, 2, 2, 1);         \
+        else if (p.row_part) PIO_WK(DTV, 0, 2, 1, 1);                \
+        else if (p.out_f32 && p.R) PIO_WK(DTV, 0, 2, 1, 0);          \
+        else if (p.out_f32) PIO_WK(DTV, 0, 2, 0, 0);                 \
+        else if (p.ln_part && p.act == 1) PIO_WK(DTV, 1, 0, 0, 2);   \
+        else if (p.ln_part) PIO_WK(DTV, 0, 0, 0, 2);                 \
+        else if (p.act == 1) PIO_WK(DTV, 1, 0, 0, 0);                \
+        else PIO_WK(DTV, 0, 0, 0, 0);                                \
     } while (0)
     if (dtype == PIO_DT_F16) PIO_WS(PIO_DT_F16);
     else PIO_WS(PIO_DT_BF16);

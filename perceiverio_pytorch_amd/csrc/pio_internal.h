@@ -92,7 +92,8 @@ int layernorm_cast_launch(const pio_tensor3_t &x, const pio_layernorm_t *ln, voi
                           int dtype, hipStream_t s);
 // LayerNorm fold: 16-bit cast of contiguous 1024-channel rows + their per-128-column (sum, sum of squares), the form
 // the fold's consumer GEMM reads (first layer of a stack: later layers get both from the producing GEMM)
-int rowstats_cast_launch(const float *x, int64_t rows, void *y16, float *part, int dtype, hipStream_t s);
+int rowstats_cast_launch(const float *x, int64_t rows, void *y16, void *y16_lo, float *part, int dtype,
+                         hipStream_t s);
 int ln_fold_enable(int on);   // returns the previous setting
 bool ln_fold_enabled();
 int softmax_rows_launch(const float *S, int64_t lds, void *P, void *P_lo, int64_t ldp, int B, int H, int Tq, int Tk,

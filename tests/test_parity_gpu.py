@@ -650,6 +650,29 @@ def test_gemm_layernorm_fold(dev, M, N2, act, dt):
     assert torch.allclose(part[:, :, 0].double(), blocks.sum(-1), rtol=1e-4, atol=1e-3)
     assert torch.allclose(part[:, :, 1].double(), (blocks * blocks).sum(-1), rtol=1e-4, atol=1e-3)
 
+    # ---- the same producer with the residual stream as a 16-bit pair in and out, no fp32 result at all
+    Rhi = Rm.to(tdt)
+    Rlo = (Rm - Rhi.float()).to(tdt)
+    Xh = torch.full((M, D), float("nan"), dtype=tdt, device=dev)
+    Xl = torch.full((M, D), float("nan"), dtype=tdt, device=dev)
+    part2 = torch.full((M, D // 128, 2), float("nan"), device=dev)
+    gq = L.Gemm()
+    gq.A, gq.B, gq.C = A.data_ptr(), W1.data_ptr(), None
+    gq.M, gq.N, gq.K = M, D, K1
+    gq.lda, gq.ldb, gq.ldc = K1, K1, D
+    gq.batch, gq.nh = 1, 1
+    gq.bias, gq.bias_mode, gq.act, gq.alpha = b1.data_ptr(), 1, 0, 1.0
+    gq.out_f32, gq.n_store, gq.dtype = 1, D, code
+    gq.X16, gq.ld16, gq.row_part = Xh.data_ptr(), D, part2.data_ptr()
+    gq.X16_lo, gq.R16_hi, gq.R16_lo = Xl.data_ptr(), Rhi.data_ptr(), Rlo.data_ptr()
+    L.check(lib.pio_gemm_nt(C.byref(gq), st), "producer (pair)")
+    torch.cuda.synchronize()
+    xref2 = A.double() @ W1.double().T + b1.double() + Rhi.double() + Rlo.double()
+    got2 = Xh.double() + Xl.double()
+    pair_tol = 2e-6 if dt == "f16" else 4e-5
+    assert ((got2 - xref2).abs().max() / xref2.abs().max()).item() <= pair_tol
+    assert torch.allclose(part2[:, :, 0].double(), got2.reshape(M, D // 128, 128).sum(-1), rtol=1e-4, atol=2e-3)
+
     # ---- consumer
     Wf = (W2 * gamma[None, :]).to(tdt)
     cvec = Wf.float().sum(1).contiguous()
