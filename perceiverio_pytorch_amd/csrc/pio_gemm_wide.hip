@@ -311,9 +311,9 @@ __global__ __launch_bounds__(256) void gemm_nt_wide(const GemmParams p, int tile
                 PIO_WSTAMP(1);
                 if (extra == 0) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
                 else if (extra == 1) asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
-                else if (extra == 2) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+                else if (extra == 10) asm volatile("s_waitcnt vmcnt(26)" ::: "memory");
                 else if (extra == 33) asm volatile("s_waitcnt vmcnt(49)" ::: "memory");
-                else if (extra == 34) asm volatile("s_waitcnt vmcnt(50)" ::: "memory");
+                else if (extra == 42) asm volatile("s_waitcnt vmcnt(58)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(63)" ::: "memory");  // (the counter's ceiling: stricter than needed)
                 PIO_WSTAMP(2);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -356,7 +356,18 @@ __global__ __launch_bounds__(256) void gemm_nt_wide(const GemmParams p, int tile
         }
         // stores of one epilogue per wave (a lower bound is enough once it exceeds the counter's ceiling) + the DMAs
         // of the bias / c rows at the head of the tile's first phase
-        constexpr int NDMA0 = LNF == 2 ? 2 : 1;
+        // (LNF == 2: + the 8 loads of the row statistics, issued here at the head of the tile and consumed in its
+        //  epilogue -- they ride through the main loop in 32 of the ~100 free VGPRs instead of exposing their latency)
+        constexpr int NDMA0 = LNF == 2 ? 10 : 1;
+        f32x4 part[8];
+        if constexpr (LNF == 2) {
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi) {
+                int m = o_m + mi * 16;
+                m = m < p.M ? m : p.M - 1;
+                part[mi] = *(const f32x4 *)(p.ln_part + ((int64_t)m * 8 + 2 * fq) * 2);
+            }
+        }
         constexpr int NSTORE = OUT == 2 ? 64 : 32;
         // (phase g waits for the pieces of phase g-3: in phases 0..2 of a tile those are older than the previous
         //  tile's stores, which may therefore stay outstanding; from phase 3 on the in-order counter makes them finish)
@@ -497,13 +508,6 @@ __global__ __launch_bounds__(256) void gemm_nt_wide(const GemmParams p, int tile
         // 2 fq and 2 fq + 1 (K == 1024: eight 128-column blocks), two butterfly steps add the four groups
         float rs[8], nmr[8];
         if constexpr (LNF == 2) {
-            f32x4 part[8];
-#pragma unroll
-            for (int mi = 0; mi < 8; ++mi) {
-                int m = o_m + mi * 16;
-                m = m < p.M ? m : p.M - 1;
-                part[mi] = *(const f32x4 *)(p.ln_part + ((int64_t)m * 8 + 2 * fq) * 2);
-            }
 #pragma unroll
             for (int mi = 0; mi < 8; ++mi) {
                 float sm = part[mi][0] + part[mi][2], sq = part[mi][1] + part[mi][3];
