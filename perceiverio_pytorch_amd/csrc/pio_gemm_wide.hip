@@ -1,5 +1,9 @@
-// gemm_nt_wide: C[M,N] = alpha * A[M,K] B[N,K]^T + bias, 16-bit out -- persistent 256x256 tiles, FOUR waves (one per
-// SIMD), each wave a 128x128 quarter with its 256 accumulator registers in AGPRs.
+// gemm_nt_wide: C[M,N] = epi(alpha * A[M,K] B[N,K]^T + bias) -- persistent 256x256 tiles, FOUR waves (one per SIMD),
+// each wave a 128x128 quarter with its 256 accumulator registers in AGPRs.  Epilogues: 16-bit out (optionally
+// erf-GELU), fp32 out (optionally + fp32 residual), and the two halves of the LayerNorm fold (template LNF): the
+// PRODUCER adds the residual given as a 16-bit pair, leaves its result as a 16-bit pair (+ fp32 if asked) together with
+// per-row partial sums; the CONSUMER turns those sums into mean / rstd and finishes LayerNorm(x) W^T + b from the
+// un-normalised 16-bit x (pio_gemm_t, pio_ln_fold_t).  It carries every weight GEMM of the latent self-attend stack.
 //
 // Why a third GEMM: the streaming kernel (pio_gemm_stream.hip, 256x128 tiles, eight waves in two teams) spends a
 // step of 1024 MFMA-cycles in ~2000 cycles: each wave alternates a load phase (16 LDS reads + 6 DMA pieces, bound
@@ -8,10 +12,10 @@
 // of 32: 64 MFMAs = 1024 cycles) it issues, BETWEEN its MFMAs, the 16 LDS reads of the next slice's fragments into
 // a second fragment register set and 8 DMA pieces of the slice four ahead -- 64 KiB of operands per 2048
 // MFMA-cycles, i.e. half the vector-memory rate and two thirds of the LDS-read bytes of the streaming kernel per
-// FLOP.  One barrier per phase.  The price: with one accumulator set the tile's result leaves in an exposed
-// epilogue (no second set to drip from), so this kernel serves the projections whose epilogue is cheap -- bias and
-// a 16-bit store (the fused q|k|v projection: 29 % of a self-attend layer) -- and the others stay on the streaming
-// kernel.
+// FLOP.  One barrier per phase, behind the phase's first eight MFMAs.  The price: with one accumulator set the tile's
+// result leaves in an exposed epilogue (no second set to drip from).  That epilogue is bound by its memory traffic,
+// not by its arithmetic (GELU or the fold's extra FMAs hide behind the stores); for the 16-bit outputs the caches
+// absorb it at ~7 TB/s, for the residual GEMMs (64 MB in, 64 MB out per launch) it is the larger half of the kernel.
 //
 // LDS: ring of 4 slices x (A 256 rows x 64 B | B 256 rows x 64 B) = 128 KiB; a row's four 16-B chunks are stored at
 // position chunk ^ f((row >> 2) & 3), f = {0, 2, 3, 1}: conflict-free for ds_read_b128's lane groups
