@@ -153,7 +153,8 @@ int pio_ln_fold_enable(int on);
 /* --- kernel selection of pio_gemm_nt, for tests and A/B benchmarks ------------------------------- */
 /* 0: automatic (default; env PIO_GEMM_TILE gives the initial value), 128: 128x128 tile, 256: 256x256 tile,
  * 1: persistent 256x128 streaming kernel wherever it is legal, 2: persistent 256x256 four-wave kernel wherever
- * it is legal.  Returns the previous setting. */
+ * it is legal, 3: the LayerNorm-fold producer on the two-workgroups-per-CU kernel (gemm_nt_duo).  Returns the
+ * previous setting. */
 int pio_gemm_kernel_override(int which);
 
 /* --- weight packing (one-off, after load_state_dict) ------------------------------------------ */

@@ -325,6 +325,17 @@ int gemm_nt_launch(const pio_gemm_t &g, hipStream_t s) {
             if (forced == 1 || forced == 128 || forced == 256) wide = false;
             const bool fold = p.X16 || p.row_part || p.ln_part || p.ln_c || p.X16_lo || p.R16_hi || p.R16_lo;
             if (fold) {
+                // the producer with 16-bit pairs in and out: two half-height workgroups per CU (override 3 / env
+                // PIO_GEMM_DUO=1), else the wide kernel
+                static const bool duo_env = [] {
+                    const char *e = getenv("PIO_GEMM_DUO");
+                    return e && atoi(e) != 0;
+                }();
+                if ((forced == 3 || (forced == 0 && duo_env)) && gemm_duo_ok(p, g.batch)) {
+                    ProfScope prof(PROF_GEMM_WIDE, algo_flops, algo_bytes, s);
+                    gemm_duo_launch(p, g.dtype, s);
+                    return launch_status();
+                }
                 if (!gemm_wide_ok(p, g.batch)) return PIO_E_SHAPE;
                 wide = true;
             }

@@ -138,4 +138,8 @@ void gemm_stream_launch(const GemmParams &p, int dtype, int batch, hipStream_t s
 bool gemm_wide_ok(const GemmParams &p, int batch);
 void gemm_wide_launch(const GemmParams &p, int dtype, hipStream_t s);
 
+// the LayerNorm fold's producer with two 128x256-tile workgroups per CU (pio_gemm_duo.hip)
+bool gemm_duo_ok(const GemmParams &p, int batch);
+void gemm_duo_launch(const GemmParams &p, int dtype, hipStream_t s);
+
 }  // namespace pio

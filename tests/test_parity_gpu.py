@@ -665,13 +665,22 @@ def test_gemm_layernorm_fold(dev, M, N2, act, dt):
     gq.out_f32, gq.n_store, gq.dtype = 1, D, code
     gq.X16, gq.ld16, gq.row_part = Xh.data_ptr(), D, part2.data_ptr()
     gq.X16_lo, gq.R16_hi, gq.R16_lo = Xl.data_ptr(), Rhi.data_ptr(), Rlo.data_ptr()
-    L.check(lib.pio_gemm_nt(C.byref(gq), st), "producer (pair)")
-    torch.cuda.synchronize()
     xref2 = A.double() @ W1.double().T + b1.double() + Rhi.double() + Rlo.double()
-    got2 = Xh.double() + Xl.double()
     pair_tol = 2e-6 if dt == "f16" else 4e-5
-    assert ((got2 - xref2).abs().max() / xref2.abs().max()).item() <= pair_tol
-    assert torch.allclose(part2[:, :, 0].double(), got2.reshape(M, D // 128, 128).sum(-1), rtol=1e-4, atol=2e-3)
+    for kernel in (0, 3):  # 0: gemm_nt_wide, 3: gemm_nt_duo (two half-height workgroups per CU)
+        Xh.fill_(float("nan")); Xl.fill_(float("nan")); part2.fill_(float("nan"))
+        prev = lib.pio_gemm_kernel_override(kernel)
+        try:
+            L.check(lib.pio_gemm_nt(C.byref(gq), st), "producer (pair)")
+            torch.cuda.synchronize()
+        finally:
+            lib.pio_gemm_kernel_override(prev)
+        got2 = Xh.double() + Xl.double()
+        assert torch.isfinite(got2).all() and torch.isfinite(part2).all(), f"kernel {kernel}"
+        assert ((got2 - xref2).abs().max() / xref2.abs().max()).item() <= pair_tol, f"kernel {kernel}"
+        assert torch.allclose(part2[:, :, 0].double(), got2.reshape(M, D // 128, 128).sum(-1), rtol=1e-4, atol=2e-3)
+        assert torch.allclose(part2[:, :, 1].double(), (got2 * got2).reshape(M, D // 128, 128).sum(-1), rtol=1e-4,
+                              atol=2e-3)
 
     # ---- consumer
     Wf = (W2 * gamma[None, :]).to(tdt)
