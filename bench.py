@@ -1,24 +1,32 @@
 #!/usr/bin/env python3
-"""Headline benchmark: PerceiverIO forward, ImageNet-224 classifier (BASELINE.json configs[1]).
+"""Headline benchmark: PerceiverIO forward on MI355X (BASELINE.json configs[1] by default).
 
-One "step" = one full forward of ClassificationPerceiver (PrepType.FOURIER_POS_CONVNET) on a batch of synthetic
-images that is already resident in HBM:
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config imagenet|language|flow|multimodal]
+
+One "step" = one full forward of the task model on synthetic inputs already resident in HBM.  Default config
+`imagenet`: ClassificationPerceiver (PrepType.FOURIER_POS_CONVNET), B = 32 per GPU:
     images [B,3,224,224] fp32 -> conv preprocessing + Fourier features (torch/MIOpen plumbing, [B,3136,322])
     -> PerceiverEncoder (cross-attend into 512x1024 latents, 8 blocks x 6 weight-shared self-attends)
-    -> PerceiverDecoder (1000 learned queries x 1024, query residual, final Linear 1024->1000)
-    -> logits of query row 0 [B,1000]
-with B = 32 per GPU.  Every decoder row is computed (as the reference does); the hot path (encoder + decoder,
-99.9 % of the FLOPs) runs in libpio_hip.so.  `--hot-path-only` times just that on a resident [B,3136,322] array.
+    -> PerceiverDecoder (1000 learned queries x 1024, query residual, final Linear 1024->1000) -> logits [B,1000]
+Every decoder row is computed (as the reference does); the hot path (encoder + decoder, 99.9 % of the FLOPs) runs in
+libpio_hip.so.  The other configs time BASELINE.json configs[2..4] (language B = 32, flow B = 1, multimodal B = 1 with
+128 output chunks) the same way.
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (one rank per GPU, RCCL)
+Multi-GPU: `--gpus N` with no WORLD_SIZE in the environment starts the N ranks itself (a child
+`python -m torch.distributed.run`, spawned BEFORE this process touches the GPU; the child's rank 0 prints the JSON
+line); under torch.distributed.run it is one rank per GPU over RCCL.  imagenet / language / multimodal shard the
+batch (weak scaling; imagenet all-gathers its logits, the path's only collective), flow (B = 1 < world) shards the
+182 528 decoder queries and all-gathers the flow field (strong scaling).
 
 Rank 0 prints ONE JSON line.  Extra objects:
-  roofline     -- the dominant kernel (gemm_nt_wide / gemm_nt_stream, the weight GEMMs of the latent stack): ALGORITHMIC flops / device
-                  time measured with HIP events around every launch of that kernel in an instrumented repeat of the
-                  step; `traffic` = HBM bytes per launch from the committed PMC profile (profiles/traffic.json)
-  cpu_baseline -- the numpy oracle ("port") of the hot path timed on this host's cores on a bounded sample
-  parity       -- in-run check of the same model at B=2 against the committed REFERENCE golden (gate 1e-3)
+  roofline     -- the dominant kernel: ALGORITHMIC flops / device time measured with HIP events around every launch of
+                  that kernel class in an instrumented repeat of the step; `traffic` = HBM bytes per launch from the
+                  committed PMC profile (profiles/traffic.json)
+  cpu_baseline -- the torch fp32 restatement of the hot path (oracle/perceiver_oracle_torch.py, "port") timed on this
+                  host's cores on a bounded sample; the numpy oracle's figure is kept as `numpy_port`
+  parity       -- in-run check of the benchmarked policy against REFERENCE goldens (gate 1e-3): for imagenet the
+                  B = 4 golden, whose 2048 latent rows take the same LayerNorm-fold path as the timed batch
+  class_default_policy -- (imagenet) the same step under the class-default policy of ClassificationPerceiver
 """
 from __future__ import annotations
 
@@ -26,6 +34,8 @@ import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -34,186 +44,364 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
-CFG = dict(M=3136, C=322, N=512, D=1024, L=6, blocks=8, xh=1, sh=8, Q=1000, Dq=1024, out=1000)
-# algorithmic GFLOP per sample of the hot path (2*m*n*k per product, reference formulation);
-# the conv preprocessing adds 0.24 GFLOP (0.06 %) and is not counted.
-GFLOP_PER_SAMPLE = 381.65
 MFMA_PEAK_TFLOPS = 2500.0    # dense fp16/bf16, MI355X_MICROARCH.md chip table
-GOLDEN = "model_classify_conv"
 SEED = 31                    # parameter seed of the committed whole-model goldens
 
+# algorithmic GFLOP per sample of the hot path (2*m*n*k per product, reference formulation)
+CONFIGS = {
+    "imagenet": dict(golden="model_classify_conv", parity_golden="model_classify_b4_s31", batch=32, policy="fp16",
+                     gflop=381.65, scaling="weak",
+                     metric="samples/sec PerceiverIO fwd (ImageNet-224, 512x1024 latents, 8 blocks x 6 self-attends)",
+                     workload="imagenet224 ClassificationPerceiver (conv+Fourier prep -> encoder 3136x322->512x1024, "
+                              "8x6 SA -> decoder 1000 queries -> final Linear), all rows computed",
+                     oracle=dict(num_blocks=8, num_self_attends_per_block=6, num_cross_attend_heads=1,
+                                 num_self_attend_heads=8, encoder_query_residual=True, decoder_heads=1,
+                                 decoder_query_residual=True, final_project=True),
+                     hot=dict(M=3136, C=322, Q=1000)),
+    "language": dict(golden="model_language", parity_golden="model_language", batch=32, policy="fp16x2w",
+                     gflop=120.1, scaling="weak",
+                     metric="samples/sec PerceiverIO fwd (masked-LM, 2048 byte tokens, 256x1280 latents, 26 self-attends)",
+                     workload="LanguagePerceiver: 2048 byte tokens (ragged valid lengths 512..2048, input + query "
+                              "masks) -> encoder 2048x768->256x1280 (8 heads), 26 SA -> decoder 2048 queries -> tied "
+                              "embedding logits [B,2048,262]",
+                     oracle=dict(num_blocks=1, num_self_attends_per_block=26, num_cross_attend_heads=8,
+                                 num_self_attend_heads=8, encoder_query_residual=True, decoder_heads=8,
+                                 decoder_query_residual=False, final_project=False),
+                     hot=dict(M=2048, C=768, Q=2048)),
+    "flow": dict(golden="model_flow_full", parity_golden="model_flow_full", batch=1, policy="fp16x3", gflop=1885.5,
+                 scaling="strong",
+                 metric="samples/sec PerceiverIO fwd (optical flow, 368x496 frame pair, 2048x512 latents, 24 self-attends)",
+                 workload="FlowPerceiver: frame pair [1,3,368,496] x2 -> 3x3 patches -> encoder 182528x322->2048x512, "
+                          "24 SA (16 heads) -> decoder 182528 per-pixel queries -> flow [1,2,368,496]",
+                 oracle=dict(num_blocks=1, num_self_attends_per_block=24, num_cross_attend_heads=1,
+                             num_self_attend_heads=16, encoder_query_residual=True, decoder_heads=1,
+                             decoder_query_residual=False, final_project=True),
+                 hot=dict(M=182528, C=322, Q=182528)),
+    "multimodal": dict(golden="model_multimodal_full", parity_golden="model_multimodal_full", batch=1, policy="fp16x3",
+                       gflop=250.1 + 128 * 57.2, scaling="weak",
+                       metric="samples/sec PerceiverIO fwd (multimodal autoencode, 16x224x224 video + audio + label, "
+                              "784x512 latents, 128 output chunks)",
+                       workload="MultiModalPerceiver: video [B,16,3,224,224] + audio [B,30720,1] + label -> encoder "
+                                "52097x704->784x512 ONCE (the reference recomputes it per chunk: 39.3 TFLOP/sample; "
+                                "executed 7.57), 8 SA -> 128 decoder chunks of 6288 queries x 1026",
+                       oracle=dict(num_blocks=1, num_self_attends_per_block=8, num_cross_attend_heads=1,
+                                   num_self_attend_heads=8, encoder_query_residual=True, decoder_heads=1,
+                                   decoder_query_residual=False, final_project=True),
+                       hot=dict(M=52097, C=704, Q=6288)),
+}
 
-def build_model(dev, policy):
-    """ClassificationPerceiver with the deterministic parameters of the committed golden (names/shapes of the
-    reference state_dict are frozen in the fixture; values come from the seeded generator)."""
-    import perceiverio_pytorch_amd as P
-    from cases import gen_state_dict
-    from perceiverio_pytorch_amd.models import ClassificationPerceiver
-    P.set_precision_policy(policy)
-    g = np.load(os.path.join(ROOT, "tests", "golden", GOLDEN + ".npz"))
-    spec = [(str(n), tuple(int(d) for d in str(s).split(",") if d != "")) for n, s in
+
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` outside torchrun: start the N ranks as a CHILD process tree before this process has
+    made any HIP call (never re-exec a process that has touched the GPU) and pass its exit code on.  The child's
+    rank 0 writes the JSON line to the inherited stdout."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def spec_of(g):
+    return [(str(n), tuple(int(d) for d in str(s).split(",") if d != "")) for n, s in
             zip(g["spec_names"], g["spec_shapes"])]
-    params = gen_state_dict(spec, SEED)
-    model = ClassificationPerceiver()
+
+
+def build_model(name, dev, policy):
+    """Task model with the deterministic parameters of the committed goldens (names / shapes of the reference
+    state_dict are frozen in the fixture; values come from the seeded generator)."""
+    import numpy as np
+    import torch
+    from cases import gen_state_dict
+    from perceiverio_pytorch_amd import models as M
+    g = np.load(os.path.join(ROOT, "tests", "golden", CONFIGS[name]["golden"] + ".npz"))
+    params = gen_state_dict(spec_of(g), SEED)
+    model = {"imagenet": M.ClassificationPerceiver, "language": M.LanguagePerceiver, "flow": M.FlowPerceiver,
+             "multimodal": M.MultiModalPerceiver}[name]()
     model.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
-    model.precision_policy = policy         # the benchmarked policy (the class default is fp16x2w)
-    return model.to(dev).eval(), params, g
+    model.precision_policy = policy
+    return model.to(dev).eval(), params
 
 
-def parity_check(model, g, dev):
-    """B=2 run on the golden's seeded images vs the reference's float32 logits frozen in tests/golden."""
-    from cases import model_inputs
-    x = torch.from_numpy(model_inputs(GOLDEN)[0]).to(dev)
-    with torch.inference_mode():
-        y = model(x).cpu().numpy().astype(np.float64)
-    ref = g["out"].astype(np.float64)
+def make_inputs(name, B, rank, dev):
+    import torch
+    gen = torch.Generator(device="cpu").manual_seed(1000 + rank)
+    if name == "imagenet":
+        return (torch.randn(B, 3, 224, 224, generator=gen).to(dev),)
+    if name == "language":
+        tok = torch.randint(6, 262, (B, 2048), generator=gen)
+        lens = torch.tensor([2048 - (b * 97) % 1536 for b in range(B)])
+        mask = torch.arange(2048)[None, :] < lens[:, None]
+        tok[~mask] = 0
+        return (tok.to(dev), mask.to(dev))
+    if name == "flow":
+        gen = torch.Generator(device="cpu").manual_seed(1000)          # (every rank sees the SAME frame pair)
+        return ((torch.rand(B, 3, 368, 496, generator=gen) * 2 - 1).to(dev),
+                (torch.rand(B, 3, 368, 496, generator=gen) * 2 - 1).to(dev))
+    if name == "multimodal":
+        return (torch.rand(B, 16, 3, 224, 224, generator=gen).to(dev),
+                (torch.rand(B, 30720, 1, generator=gen) * 2 - 1).to(dev))
+    raise ValueError(name)
+
+
+def rel_errors(y, ref, absmax=None):
+    import numpy as np
+    y = np.asarray(y, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
     d = y - ref
-    return float(np.sqrt((d * d).sum()) / np.sqrt((ref * ref).sum())), float(np.abs(d).max() / np.abs(ref).max())
+    am = float(absmax) if absmax is not None else np.abs(ref).max()
+    return float(np.sqrt((d * d).sum()) / np.sqrt((ref * ref).sum())), float(np.abs(d).max() / am)
+
+
+def parity_check(name, model, params, dev, policy):
+    """The benchmarked policy against REFERENCE outputs frozen in tests/golden (generated by oracle/make_goldens.py
+    from the real reference): relL2 and max-abs / abs-max, gate 1e-3."""
+    import numpy as np
+    import torch
+    from cases import MODEL_CASES, model_inputs
+    from perceiverio_pytorch_amd.runtime import precision
+    gname = CONFIGS[name]["parity_golden"]
+    g = np.load(os.path.join(ROOT, "tests", "golden", gname + ".npz"))
+    ins = [torch.from_numpy(a).to(dev) for a in model_inputs(gname)]
+    out = {"tol": 1e-3, "golden": f"tests/golden/{gname}.npz (reference fp32 outputs)"}
+    with torch.inference_mode():
+        if name == "imagenet":
+            y = model(ins[0]).cpu().numpy()
+            rl2, rmax = rel_errors(y, g["out"])
+            out["case"] = "ClassificationPerceiver B=4 (2048 latent rows: same LayerNorm-fold path as the timed batch)"
+        elif name == "language":
+            y = model(ins[0], ins[1]).cpu().numpy()
+            rl2, rmax = rel_errors(y[:, :96], g["out"], g["out_absmax"])
+            out["case"] = "LanguagePerceiver B=2 (60 / 700 valid tokens), logits rows 0..95"
+        elif name == "flow":
+            y = model(ins[0], ins[1]).cpu().numpy()
+            rl2, rmax = rel_errors(y[:, :, ::8, ::8], g["out_sub"], g["out_absmax"])
+            out["case"] = "FlowPerceiver full size, 8x sub-sampled flow field"
+        else:
+            c = MODEL_CASES[gname]
+            images, audio = ins
+            b, t, ch, h, w = images.shape
+            k = c["chunks"][0]
+            ics = t * h * w // c["n_chunks"]
+            acs = audio.shape[1] // model.audio_samples_per_patch // c["n_chunks"]
+            sub = {"image": torch.arange(ics * k, ics * (k + 1)), "audio": torch.arange(acs * k, acs * (k + 1)),
+                   "label": None}
+            with precision(policy):
+                o = model.perceiver({"image": images, "audio": audio,
+                                     "label": torch.zeros((b, model.num_classes), device=dev)},
+                                    subsampled_output_points=sub)
+            rl2, rmax = rel_errors(o["image"].cpu().numpy(), g[f"out_image_{k}"])
+            out["case"] = "MultiModalPerceiver full size, output chunk 0 of 128 (image reconstruction rows)"
+    out.update(relL2=rl2, max_abs_over_absmax=rmax, ok=bool(rl2 <= 1e-3 and rmax <= 1e-3))
+    return out
 
 
 def cpu_threads():
-    """Threads the numpy oracle can actually use: the BLAS pool size (threadpoolctl) capped by this process's CPU
-    affinity -- not os.cpu_count(), which reports the whole host even inside a 16-CPU share."""
     try:
-        avail = len(os.sched_getaffinity(0))
+        return len(os.sched_getaffinity(0))
     except AttributeError:
-        avail = os.cpu_count() or 1
+        return os.cpu_count() or 1
+
+
+def cpu_model():
     try:
-        from threadpoolctl import threadpool_info
-        pools = [p.get("num_threads", 0) for p in threadpool_info() if p.get("user_api") == "blas"]
-        if pools:
-            return min(avail, max(pools))
-    except Exception:  # noqa: BLE001
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
         pass
-    return avail
+    return "unknown"
 
 
-def cpu_baseline(params, sample_b):
-    """numpy oracle of the hot path (encoder + decoder) on a [B,3136,322] sample, same parameters."""
+def cpu_baseline(name, params, sample_b):
+    """The hot path (encoder + decoder) on this host's cores: torch fp32 restatement (oracle/perceiver_oracle_torch.py,
+    the same eager ATen ops the reference runs on a CPU), torch.set_num_threads(affinity), same parameters, a bounded
+    sample of the same workload.  Returns the cpu_baseline object."""
+    import numpy as np
+    import torch
+    import perceiver_oracle_torch as OT
+    from cases import _rand
+    cfg = CONFIGS[name]
+    hot, kw = cfg["hot"], cfg["oracle"]
+    nthr = cpu_threads()
+    torch.set_num_threads(nthr)
+    enc = OT.to_torch({k[len("perceiver._encoder."):]: v for k, v in params.items() if k.startswith("perceiver._encoder.")})
+    dec = OT.to_torch({k[len("perceiver._decoder."):]: v for k, v in params.items() if k.startswith("perceiver._decoder.")})
+    x = torch.from_numpy(_rand("cpu_baseline_x", (sample_b, hot["M"], hot["C"]), SEED))
+    ekw = dict(num_blocks=kw["num_blocks"], num_self_attends_per_block=kw["num_self_attends_per_block"],
+               num_cross_attend_heads=kw["num_cross_attend_heads"], num_self_attend_heads=kw["num_self_attend_heads"],
+               use_query_residual=kw["encoder_query_residual"])
+    dkw = dict(num_heads=kw["decoder_heads"], use_query_residual=kw["decoder_query_residual"],
+               final_project=kw["final_project"])
+    if name == "flow":
+        query = lambda xx: xx                                                    # noqa: E731  (output_queries.py:76-77)
+    elif name == "multimodal":
+        qq = torch.from_numpy(_rand("cpu_baseline_q", (1, hot["Q"], 1026), SEED))
+        query = lambda xx: qq.expand(xx.shape[0], -1, -1)                        # noqa: E731
+    else:
+        key = "perceiver._output_queries.__default._position_encoding.pos_embs"
+        qt = torch.from_numpy(params[key])
+        query = lambda xx: torch.broadcast_to(qt[None], (xx.shape[0],) + tuple(qt.shape))   # noqa: E731
+    with torch.inference_mode():
+        if name == "imagenet":
+            z = OT.encoder(enc, x[:1], **ekw)                                    # warm-up (thread pool, page-in)
+            OT.decoder(dec, query(x[:1]), z, **dkw)
+        t0 = time.perf_counter()
+        z = OT.encoder(enc, x, **ekw)
+        t1 = time.perf_counter()
+        OT.decoder(dec, query(x), z, **dkw)
+        t2 = time.perf_counter()
+    t_enc, t_dec = t1 - t0, t2 - t1
+    if name == "multimodal":
+        total = t_enc + 128 * t_dec
+        sample = (f"torch fp32 restatement of the hot path, B={sample_b}: encoder once {t_enc:.1f} s + ONE of 128 decoder "
+                  f"chunks {t_dec:.2f} s, extrapolated to encode-once + 128 chunks = {total:.0f} s per sample")
+    else:
+        total = t_enc + t_dec
+        sample = (f"torch fp32 restatement of the hot path (encoder+decoder, >= 99.9 % of the model's FLOPs), same "
+                  f"parameters, B={sample_b}, one forward ({total:.1f} s)")
+    return {"value": sample_b / total, "unit": "samples/s", "cores": nthr, "kind": "port", "sample": sample,
+            "cpu_model": cpu_model(), "torch_threads": torch.get_num_threads()}
+
+
+def numpy_baseline(params, sample_b):
+    """Secondary figure: the numpy oracle (the checker the parity tests use) on the imagenet hot path."""
     import perceiver_oracle as O
     from cases import _rand
+    cfg = CONFIGS["imagenet"]
     enc = {k[len("perceiver._encoder."):]: v for k, v in params.items() if k.startswith("perceiver._encoder.")}
     dec = {k[len("perceiver._decoder."):]: v for k, v in params.items() if k.startswith("perceiver._decoder.")}
     qtab = params["perceiver._output_queries.__default._position_encoding.pos_embs"]
-    kw = dict(num_blocks=CFG["blocks"], num_self_attends_per_block=CFG["L"], num_cross_attend_heads=1,
-              num_self_attend_heads=CFG["sh"], encoder_query_residual=True, decoder_heads=1,
-              decoder_query_residual=True, final_project=True)
-    x = _rand("cpu_baseline_x", (sample_b, CFG["M"], CFG["C"]), SEED)
-    O.encode_decode(enc, dec, x[:1], qtab, **kw)            # warm-up (BLAS threads, page-in)
+    x = _rand("cpu_baseline_x", (sample_b, cfg["hot"]["M"], cfg["hot"]["C"]), SEED)
     t0 = time.perf_counter()
-    O.encode_decode(enc, dec, x, qtab, **kw)
+    O.encode_decode(enc, dec, x, qtab, **cfg["oracle"])
     dt = time.perf_counter() - t0
-    return sample_b / dt, dt
+    return {"value": sample_b / dt, "unit": "samples/s", "sample": f"numpy fp32 oracle, B={sample_b}, {dt:.1f} s"}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=32, help="samples per GPU per step")
-    ap.add_argument("--policy", default=os.environ.get("PIO_BENCH_POLICY", "fp16"))
-    ap.add_argument("--cpu-sample", type=int, default=4, help="batch of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="imagenet")
+    ap.add_argument("--batch", type=int, default=None, help="samples per GPU per step (flow: total)")
+    ap.add_argument("--policy", default=os.environ.get("PIO_BENCH_POLICY"))
+    ap.add_argument("--cpu-sample", type=int, default=None, help="batch of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-parity", action="store_true")
-    ap.add_argument("--hot-path-only", action="store_true", help="time encoder+decoder on a resident [B,3136,322] array")
+    ap.add_argument("--no-extras", action="store_true", help="skip stage timing and the class-default policy leg")
+    ap.add_argument("--hot-path-only", action="store_true", help="imagenet: time encoder+decoder on a resident [B,3136,322] array")
     args = ap.parse_args()
+
+    # PIO_BENCH_REHEARSE=1 (1-GPU box): go through the same spawn + multi-rank code with every rank on cuda:0 and the
+    # gloo backend (RCCL refuses two ranks on one device) -- a rehearsal of the control flow, not a measurement
+    rehearse = os.environ.get("PIO_BENCH_REHEARSE", "0") == "1"
+    if (args.gpus > 1 or rehearse) and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))                   # (nothing in this process has touched the GPU yet)
+
+    import numpy as np
+    import torch
+
+    cfg = CONFIGS[args.config]
+    name = args.config
+    heavy = name in ("flow", "multimodal")
+    steps = args.steps if args.steps is not None else (3 if heavy else 20)
+    warmup = args.warmup if args.warmup is not None else (1 if heavy else 5)
+    policy = args.policy or cfg["policy"]
+    B = args.batch or cfg["batch"]
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world == 1 and args.gpus > 1:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", 0 if rehearse else local_rank)
     torch.cuda.set_device(dev)
     dist = None
     if world > 1:
         import torch.distributed as dist_
         dist = dist_
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # nccl == RCCL on ROCm
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # nccl == RCCL on ROCm
 
     import perceiverio_pytorch_amd as P
     from perceiverio_pytorch_amd import _lib as L
+    from perceiverio_pytorch_amd.dist import all_gather_rows
     lib = P.lib()
     assert lib.pio_arch_ok() == 1, "libpio_hip.so is gfx950-only"
+    P.set_precision_policy(policy)
 
-    model, params, golden = build_model(dev, args.policy)
-    B = args.batch
-    gen = torch.Generator(device="cpu").manual_seed(1000 + rank)
+    model, params = build_model(name, dev, policy)
+    inputs = make_inputs(name, B, rank, dev)               # resident in HBM before the timed region
+    if name == "flow" and world > 1:
+        model.query_shard = (rank, world)                  # B = 1 < world: shard the decoder queries (dist.py)
     if args.hot_path_only:
-        x = torch.randn(B, CFG["M"], CFG["C"], generator=gen).to(dev)
+        assert name == "imagenet"
+        gen = torch.Generator(device="cpu").manual_seed(1000 + rank)
+        inputs = (torch.randn(B, cfg["hot"]["M"], cfg["hot"]["C"], generator=gen).to(dev),)
         pio = model.perceiver
         qtab = pio._output_queries["__default"]._position_encoding.pos_embs
 
         def forward(inp):
-            z = pio._encoder(inp, pio._encoder.latents(inp))
-            return pio._decoder(torch.broadcast_to(qtab[None], (inp.shape[0],) + qtab.shape), z)[:, 0, :]
+            with P.runtime.precision(policy):
+                z = pio._encoder(inp, pio._encoder.latents(inp))
+                return pio._decoder(torch.broadcast_to(qtab[None], (inp.shape[0],) + qtab.shape), z)[:, 0, :]
     else:
-        x = torch.randn(B, 3, 224, 224, generator=gen).to(dev)     # resident in HBM before the timed region
         forward = model
 
     parity = None
     if not args.no_parity and rank == 0:
-        rl2, rmax = parity_check(model, golden, dev)
-        parity = {"relL2": rl2, "max_abs_over_absmax": rmax, "tol": 1e-3,
-                  "case": "ClassificationPerceiver B=2 vs reference fp32 logits (tests/golden/model_classify_conv.npz)",
-                  "ok": bool(rl2 <= 1e-3 and rmax <= 1e-3)}
-        if not parity["ok"]:
-            raise SystemExit(f"parity gate failed for policy {args.policy}: {parity}")
-        # The golden case has 1024 latent rows, below the 2048 from which the SelfAttention blocks fold their
-        # LayerNorms into the GEMMs (pio_ln_fold_t): check THIS run's batch against the same model under the
-        # float32-grade policy fp16x3 (three MFMA sweeps, no fold; 2e-6 against the reference on the golden case)
-        if not args.hot_path_only and args.policy != "fp16x3":
-            with torch.inference_mode():
-                y_run = model(x).double()
-                model.precision_policy = "fp16x3"
-                y_ref = model(x).double()
-                model.precision_policy = args.policy
-            frel = float(((y_run - y_ref).norm() / y_ref.norm()).item())
-            fold_on = lib.pio_ln_fold_enable(1)     # (returns the previous setting: read it and put it back)
+        parity = parity_check(name, model, params, dev, policy)
+        if name == "imagenet":
+            fold_on = lib.pio_ln_fold_enable(1)            # (returns the previous setting: read it and put it back)
             lib.pio_ln_fold_enable(fold_on)
-            parity["bench_batch_vs_fp16x3"] = {"relL2": frel, "tol": 1e-3, "batch": B, "layernorm_fold": bool(fold_on)}
-            if frel > 1e-3:
-                raise SystemExit(f"parity gate failed on the benchmarked batch: {parity}")
-
-    gathered = [torch.empty(B, CFG["out"], device=dev) for _ in range(world)] if world > 1 else None
+            parity["layernorm_fold"] = bool(fold_on) and policy in ("fp16", "bf16")
+        if not parity["ok"]:
+            raise SystemExit(f"parity gate failed for policy {policy}: {parity}")
 
     def step():
-        logits = forward(x)                                   # [B,1000]: query row 0 (ClassificationPostprocessor)
-        if world > 1:
-            dist.all_gather(gathered, logits.contiguous())    # the path's only collective (RCCL over xGMI);
-            # same call as perceiverio_pytorch_amd.dist.all_gather_rows, with the receive list pre-allocated
-        return logits
+        out = forward(*inputs)
+        if world > 1 and name == "imagenet":
+            out = all_gather_rows(out)                     # the path's only collective (RCCL over xGMI): [B*W, 1000]
+        return out
 
     def sync():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    with torch.inference_mode():
-        for _ in range(args.warmup):
+    def timed_region(nwarm, nsteps):
+        for _ in range(nwarm):
             step()
         sync()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(nsteps):
             step()
         sync()
-        elapsed = time.perf_counter() - t0
+        el = time.perf_counter() - t0
         if world > 1:
-            t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            t = torch.tensor([el], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
+            el = float(t.item())
+        return el
+
+    NCLS = 9  # PIO_PROF_CLASSES
+    with torch.inference_mode():
+        elapsed = timed_region(warmup, steps)
 
         # ---- instrumented repeat: HIP events around every kernel launch (same stream), per kernel class ----
-        nprof = max(1, min(3, args.steps))
-        L.check(lib.pio_prof_begin(4096 * nprof), "pio_prof_begin")
+        nprof = 1 if heavy else max(1, min(3, steps))
+        L.check(lib.pio_prof_begin(16384 * nprof), "pio_prof_begin")
         for _ in range(nprof):
             step()
-        NCLS = 9  # PIO_PROF_CLASSES
         ms = (C.c_double * NCLS)()
         fl = (C.c_double * NCLS)()
         by = (C.c_double * NCLS)()
@@ -221,48 +409,63 @@ def main():
         nrec = lib.pio_prof_end(ms, fl, by, ln)
         assert nrec > 0, nrec
 
-        # ---- per-stage timing of the three hot-path stages (HIP events on the launch stream, 5 repeats each) ----
-        pio = model.perceiver
-        with P.runtime.precision(args.policy):
-            xin = pio._multi_preprocessor({"__default": x})[0] if not args.hot_path_only else x
-            lat0 = pio._encoder.latents(xin)
-            enc = pio._encoder
+        stages = None
+        class_default = None
+        if name == "imagenet" and not args.no_extras:
+            # ---- per-stage timing of the three hot-path stages (HIP events on the launch stream) ----
+            pio = model.perceiver
+            with P.runtime.precision(policy):
+                x = inputs[0]
+                xin = pio._multi_preprocessor({"__default": x})[0] if not args.hot_path_only else x
+                lat0 = pio._encoder.latents(xin)
+                enc = pio._encoder
 
-            def timed(fn, n=5):
-                fn()
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                for _ in range(n):
+                def timed(fn, n=5):
                     fn()
-                e1.record()
-                torch.cuda.synchronize()
-                return e0.elapsed_time(e1) / n
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(n):
+                        fn()
+                    e1.record()
+                    torch.cuda.synchronize()
+                    return e0.elapsed_time(e1) / n
 
-            t_cross = timed(lambda: enc.cross_attend(lat0, xin))
-            # one self-attend layer as it runs INSIDE the stack (row statistics of the LayerNorm fold carried from
-            # block to block): (whole encoder - its cross-attend) / layers
-            t_enc = timed(lambda: enc(xin, lat0), n=3)
-            t_sa = (t_enc - t_cross) / (CFG["L"] * CFG["blocks"])
-            zf = enc(xin, lat0)
-            qtab_ = pio._output_queries["__default"]._position_encoding.pos_embs
-            qv = torch.broadcast_to(qtab_[None], (B,) + qtab_.shape)
-            t_dec = timed(lambda: pio._decoder(qv, zf))
+                t_cross = timed(lambda: enc.cross_attend(lat0, xin))
+                # one self-attend layer as it runs INSIDE the stack (row statistics of the LayerNorm fold carried
+                # from block to block): (whole encoder - its cross-attend) / layers
+                t_enc = timed(lambda: enc(xin, lat0), n=3)
+                t_sa = (t_enc - t_cross) / 48
+                zf = enc(xin, lat0)
+                qtab_ = pio._output_queries["__default"]._position_encoding.pos_embs
+                qv = torch.broadcast_to(qtab_[None], (B,) + qtab_.shape)
+                t_dec = timed(lambda: pio._decoder(qv, zf))
+            # algorithmic work per sample; encoder cross-attend bytes = fp32 input M*C*4 + fp32 latents
+            # out N*D*4 (+ 5.9 MB of weights once per batch)
+            enc_bytes = B * (3136 * 322 * 4 + 512 * 1024 * 4) + 5.9e6
+            stages = {
+                "encoder_cross_attend": {"ms": t_cross, "algo_tflops": 6.191e9 * B / (t_cross * 1e-3) / 1e12,
+                                         "algo_gbps": enc_bytes / (t_cross * 1e-3) / 1e9,
+                                         "hbm_frac_of_8TBps": enc_bytes / (t_cross * 1e-3) / 8e12},
+                "self_attend_layer": {"ms": t_sa, "algo_tflops": 7.516e9 * B / (t_sa * 1e-3) / 1e12,
+                                      "mfma_frac": 7.516e9 * B / (t_sa * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS,
+                                      "x_layers": 48},
+                "decoder_and_final": {"ms": t_dec, "algo_tflops": (12.633e9 + 2.048e9) * B / (t_dec * 1e-3) / 1e12},
+            }
+            # ---- the same step under the class-default policy of ClassificationPerceiver (what a user gets without
+            # ---- choosing a policy)
+            from perceiverio_pytorch_amd.models import DEFAULT_POLICY
+            dflt = DEFAULT_POLICY["ClassificationPerceiver"]
+            if dflt != policy and not args.hot_path_only:
+                model.precision_policy = dflt
+                el2 = timed_region(2, max(3, steps // 2))
+                model.precision_policy = policy
+                n2 = max(3, steps // 2)
+                class_default = {"policy": dflt, "value": world * B * n2 / el2, "unit": "samples/s",
+                                 "ms_per_step": el2 / n2 * 1e3}
 
-    # algorithmic work per sample: FLOPs = 2mnk per product; encoder cross-attend bytes =
-    # fp32 input M*C*4 + fp32 latents out N*D*4 (+ 5.9 MB of weights once per batch)
-    enc_bytes = B * (CFG["M"] * CFG["C"] * 4 + CFG["N"] * CFG["D"] * 4) + 5.9e6
-    stages = {
-        "encoder_cross_attend": {"ms": t_cross, "algo_tflops": 6.191e9 * B / (t_cross * 1e-3) / 1e12,
-                                 "algo_gbps": enc_bytes / (t_cross * 1e-3) / 1e9,
-                                 "hbm_frac_of_8TBps": enc_bytes / (t_cross * 1e-3) / 8e12},
-        "self_attend_layer": {"ms": t_sa, "algo_tflops": 7.516e9 * B / (t_sa * 1e-3) / 1e12,
-                              "mfma_frac": 7.516e9 * B / (t_sa * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS,
-                              "x_layers": CFG["L"] * CFG["blocks"]},
-        "decoder_and_final": {"ms": t_dec, "algo_tflops": (12.633e9 + 2.048e9) * B / (t_dec * 1e-3) / 1e12},
-    }
-
-    ms_per_step = elapsed / args.steps * 1e3
-    value = world * B * args.steps / elapsed
+    ms_per_step = elapsed / steps * 1e3
+    samples_per_step = B if (name == "flow") else world * B
+    value = samples_per_step * steps / elapsed
     names = ["gemm_nt_256", "gemm_nt_128_batched", "layernorm_cast", "softmax", "pack", "flash_attn",
              "gemm_nt_128_flat", "gemm_nt_stream", "gemm_nt_wide"]
     kernels = {}
@@ -272,53 +475,64 @@ def main():
                            "avg_us": ms[i] / ln[i] * 1e3,
                            "algo_tflops": (fl[i] / (ms[i] * 1e-3) / 1e12) if fl[i] else None,
                            "algo_gbps": by[i] / (ms[i] * 1e-3) / 1e9}
-    # the dominant kernel: the MFMA kernel class with the most device time per step (the persistent 256x256 GEMM with
-    # the fused q|k|v and fc1 projections of the latent stack, or the streaming GEMM with its out / fc2 projections)
+    # the dominant kernel: the MFMA kernel class with the most device time per step
     dom = max((i for i in range(NCLS) if ln[i] and fl[i]), key=lambda i: ms[i])
     g = kernels[names[dom]]
     # HBM traffic of that kernel per launch: PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes of
     # this same command, gfx950 correction of MI355X_MICROARCH.md) condensed into profiles/traffic.json
     traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-            traffic = json.load(f)["pio::" + names[dom]]["bytes_per_launch"]
-    except Exception:  # noqa: BLE001  (no committed profile yet)
-        traffic = None
-    what = {"gemm_nt_wide": "the weight GEMMs of the latent stack: fused q|k|v, out, fc1 (GELU), fc2 projections with the "
-                            "LayerNorms folded into them, and the decoder projections",
-            "gemm_nt_stream": "weight GEMMs of the latent stack"}.get(names[dom], "")
+    if name == "imagenet":
+        try:
+            with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+                traffic = json.load(f)["pio::" + names[dom]]["bytes_per_launch"]
+        except Exception:  # noqa: BLE001  (no committed profile yet)
+            traffic = None
+    what = {"gemm_nt_wide": "persistent 256x256-tile GEMM: the weight GEMMs of the latent stack (fused q|k|v, out, fc1 "
+                            "(GELU), fc2 with the LayerNorms folded into them) and the decoder projections",
+            "gemm_nt_stream": "persistent 256x128-tile streaming GEMM", "flash_attn": "fused attention",
+            "gemm_nt_256": "256x256-tile GEMM", "gemm_nt_128_flat": "128x128-tile GEMM",
+            "gemm_nt_128_batched": "batched 128x128-tile GEMM (materialised attention products)"}.get(names[dom], "")
     roofline = {"kernel": f"pio::{names[dom]} ({what})",
                 "bound": "mfma", "achieved": g["algo_tflops"], "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": g["algo_tflops"] / MFMA_PEAK_TFLOPS, "traffic": traffic,
                 "avg_launch_us": g["avg_us"], "launches_per_step": g["launches_per_step"],
                 "algo_flops_per_launch": fl[dom] / ln[dom], "algo_bytes_per_launch": by[dom] / ln[dom]}
 
-    workload = ("imagenet224 ClassificationPerceiver (conv+Fourier prep -> encoder 3136x322->512x1024, 8x6 SA -> decoder "
-                "1000 queries -> final Linear), all rows computed")
+    workload = cfg["workload"]
     if args.hot_path_only:
         workload = "hot path only (encoder + decoder + final Linear) on a resident [B,3136,322] array"
+    par = {"imagenet": f"dp{world} (batch sharded, all-gather of logits)",
+           "language": f"dp{world} (batch sharded, outputs stay sharded)",
+           "multimodal": f"dp{world} (batch sharded, outputs stay sharded)",
+           "flow": f"qp{world} (encoder replicated, decoder queries sharded, all-gather of the flow field)"}[name]
     out = {
-        "metric": "samples/sec PerceiverIO fwd (ImageNet-224, 512x1024 latents, 8 blocks x 6 self-attends)",
-        "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f16" if args.policy.startswith("fp16") else "bf16", "data": "synthetic",
-        "config": {"workload": workload, "batch_per_gpu": B, "global_batch": B * world,
-                   "precision_policy": args.policy,
-                   "parallelism": f"dp{world} (batch sharded, all-gather of logits)"},
+        "metric": cfg["metric"],
+        "value": value, "unit": "samples/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": cfg["scaling"], "vs_baseline": None,
+        "dtype": "f16" if policy.startswith("fp16") else "bf16", "data": "synthetic",
+        "config": {"workload": workload, "batch_per_gpu": B if name != "flow" else None, "global_batch": samples_per_step,
+                   "precision_policy": policy, "parallelism": par},
+        "precision_policy": policy,
         "per_gpu": value / world,
-        "model_algo_tflops": value * GFLOP_PER_SAMPLE / 1e3,
-        "model_mfma_frac": value / world * GFLOP_PER_SAMPLE / 1e3 / MFMA_PEAK_TFLOPS,
-        "roofline": roofline, "stages": stages, "kernels": kernels, "parity": parity,
+        "model_algo_tflops": value * cfg["gflop"] / 1e3,
+        "model_mfma_frac": value / world * cfg["gflop"] / 1e3 / MFMA_PEAK_TFLOPS,
+        "roofline": roofline, "kernels": kernels, "parity": parity,
     }
-    if rank == 0 and world == 1 and args.cpu_sample > 0:
-        v, dt = cpu_baseline(params, args.cpu_sample)
-        out["cpu_baseline"] = {"value": v, "unit": "samples/s", "cores": cpu_threads(), "kind": "port",
-                               "sample": f"numpy fp32 oracle of the hot path (encoder+decoder, 99.9% of the model's "
-                                         f"FLOPs), same parameters, B={args.cpu_sample}, one forward ({dt:.1f} s) after "
-                                         f"a B=1 warm-up"}
+    if stages is not None:
+        out["stages"] = stages
+    if class_default is not None:
+        out["class_default_policy"] = class_default
+    if rank == 0 and world == 1:
+        nb = args.cpu_sample if args.cpu_sample is not None else {"imagenet": 8, "language": 4, "flow": 1,
+                                                                  "multimodal": 1}[name]
+        if nb > 0:
+            out["cpu_baseline"] = cpu_baseline(name, params, nb)
+            if name == "imagenet":
+                out["cpu_baseline"]["numpy_port"] = numpy_baseline(params, 2)
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

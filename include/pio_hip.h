@@ -9,8 +9,10 @@
  *
  * Conventions
  *   - plain C, no torch / HIP types in signatures: `stream` is a hipStream_t passed as void*.
- *   - every pointer is a DEVICE pointer owned by the caller; nothing is allocated or freed here and
- *     there is no global mutable state => calls are thread-safe per (stream, workspace).
+ *   - every pointer is a DEVICE pointer owned by the caller; compute calls allocate and free nothing and
+ *     keep no state between calls => they are thread-safe per (stream, workspace).  The only process-wide
+ *     mutable state is opt-in tooling, none of it thread-safe: the per-launch profiler (pio_prof_*) and the
+ *     two A/B switches pio_ln_fold_enable / pio_gemm_kernel_override (set them before concurrent use).
  *   - scratch memory is caller-provided: query pio_*_workspace_bytes() first.
  *   - tensors at the boundary are float32, last dimension contiguous; batch / row strides are given
  *     in ELEMENTS (a batch stride of 0 is a broadcast view, e.g. the latent table of
@@ -134,9 +136,11 @@ int pio_arch_ok(void);
 const char *pio_error_string(int code);
 
 /* --- per-launch timing for benchmarks (NOT thread-safe, off by default) ------------------------ */
-/* classes: 0 gemm_nt_256, 1 batched gemm_nt_128, 2 layernorm/cast, 3 softmax, 4 pack, 5 fused attention,
- *          6 flat gemm_nt_128, 7 gemm_nt_stream (persistent streaming kernel: the latent stack's weight GEMMs),
- *          8 gemm_nt_wide (persistent 256x256 four-wave kernel: the fused q|k|v projection) */
+/* classes: 0 gemm_nt_256 (flat 256x256 tiles), 1 batched gemm_nt_128 (materialised attention products),
+ *          2 layernorm / cast / row statistics, 3 softmax_rows, 4 pack, 5 fused attention (flash_attn),
+ *          6 flat gemm_nt_128 (small / ragged problems), 7 gemm_nt_stream (persistent 256x128 tiles: fp32 + residual
+ *          projections outside a folded stack), 8 gemm_nt_wide / gemm_nt_duo (persistent 256x256 four-wave kernel:
+ *          every weight GEMM of the latent self-attend stack -- q|k|v, out, fc1, fc2 -- and the decoder projections) */
 #define PIO_PROF_CLASSES 9
 /* Start recording a HIP-event pair around every kernel launch (up to max_records launches). */
 int pio_prof_begin(int32_t max_records);

@@ -4,7 +4,7 @@ imported in the build container (timm is not installed; SURVEY.md section 8c / A
 Written from scratch to the documented timm-0.5.4 signatures.  None of these functions
 takes part in forward arithmetic, and every parity check overwrites all parameters through
 ``load_state_dict`` -- so the distributions produced here do not influence any golden vector.
-TEST INFRASTRUCTURE: used only by oracle/pin_against_reference.py and oracle/make_goldens.py.
+TEST INFRASTRUCTURE: used only by oracle/make_goldens.py.
 """
 import math
 

@@ -305,7 +305,7 @@ if __name__ == "__main__" and not (sys.argv[1:] and all(a.startswith("model_") f
 # whole models ("next" rows): reference task models with generated parameters -> outputs
 # ------------------------------------------------------------------------------------
 def case_models(only=None):
-    from cases import MODEL_CASES, gen_state_dict, model_inputs
+    from cases import MODEL_CASES, gen_state_dict, model_inputs, model_seed
     from perceiver_io.classification_perceiver import ClassificationPerceiver, PrepType
     from perceiver_io.flow_perceiver import FlowPerceiver
     from perceiver_io.language_perceiver import LanguagePerceiver
@@ -321,7 +321,7 @@ def case_models(only=None):
                      "MultiModalPerceiver": MultiModalPerceiver}[c["cls"]](**kw)
         sd = model.state_dict()
         spec = [(k, tuple(v.shape)) for k, v in sd.items()]
-        params = gen_state_dict(spec, 31)
+        params = gen_state_dict(spec, model_seed(name))
         model.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
         model.eval()
         ins = model_inputs(name)
@@ -339,6 +339,24 @@ def case_models(only=None):
                 out_test = model(tin[0], tin[1], test_mode=True, min_overlap=10).numpy()
                 save.update(out_train=out_train, out_test=out_test)
                 print(f"{name:42s} train {out_train.shape} test {out_test.shape}")
+            elif name == "model_multimodal_full":
+                # single output chunks of the reference's loop (multimodal_perceiver.py:146-157): the perceiver call
+                # the reference makes for chunk k, nothing else
+                images, audio = tin
+                b, t, ch, h, w = images.shape
+                n_chunks = c["n_chunks"]
+                ics = t * h * w // n_chunks
+                acs = audio.shape[1] // model.audio_samples_per_patch // n_chunks
+                for k in c["chunks"]:
+                    sub = {"image": torch.arange(ics * k, ics * (k + 1)), "audio": torch.arange(acs * k, acs * (k + 1)),
+                           "label": None}
+                    out = model.perceiver({"image": images, "audio": audio,
+                                           "label": torch.zeros((b, model.num_classes))},
+                                          subsampled_output_points=sub)
+                    save.update({f"out_image_{k}": out["image"].numpy(), f"out_audio_{k}": out["audio"].numpy(),
+                                 f"out_label_{k}": out["label"].numpy()})
+                    print(f"{name:42s} chunk {k}: image {tuple(out['image'].shape)} audio {tuple(out['audio'].shape)} "
+                          f"label {tuple(out['label'].shape)} absmax {out['image'].abs().max():.3f}")
             elif c["cls"] == "MultiModalPerceiver":
                 out = model(tin[0], tin[1], n_chunks=2)
                 save.update(out_image=out["image"].numpy(), out_audio=out["audio"].numpy(),

@@ -301,8 +301,19 @@ int gemm_nt_launch(const pio_gemm_t &g, hipStream_t s) {
     const bool attn = g.batch > 1;
     const double elems = (double)g.batch * ((double)g.M * g.K + (double)g.N * g.K);
     const double algo_flops = 2.0 * g.M * g.N * (double)g.K * g.batch;
-    const double algo_bytes = 2.0 * elems + (double)g.batch * g.M * g.N * (g.out_f32 ? 4.0 : 2.0) +
-                              (g.R ? 4.0 * g.M * g.N * g.batch : 0.0);
+    // algorithmic bytes: operands once (every precision sweep reads its own image), the result in every form it
+    // leaves in (fp32 C if written, 16-bit C [+ C_lo], the LayerNorm fold's 16-bit pair X16 [+ X16_lo] and row sums),
+    // the residual in the form it arrives in (fp32 R or the 16-bit pair R16_hi + R16_lo), the consumer's row sums
+    const double mn = (double)g.batch * g.M * g.N;
+    double algo_bytes = 2.0 * elems + (g.B_lo ? 2.0 * g.batch * (double)g.N * g.K : 0.0) +
+                        (g.A_lo ? 2.0 * g.batch * (double)g.M * g.K : 0.0);
+    if (g.out_f32) algo_bytes += g.C ? 4.0 * mn : 0.0;
+    else algo_bytes += (g.C_lo ? 4.0 : 2.0) * mn;
+    if (g.X16) algo_bytes += (g.X16_lo ? 4.0 : 2.0) * mn;
+    if (g.row_part) algo_bytes += 8.0 * g.M * (double)(g.N / 128);
+    if (g.R16_hi) algo_bytes += 4.0 * mn;
+    else if (g.R) algo_bytes += 4.0 * mn;
+    if (g.ln_part) algo_bytes += 64.0 * g.M;
     // Large problems go to the 256x256-tile / 4-slot-ring kernel: enough rows, and an N that fills whole
     // 256-column tiles reasonably (<= 25 % padding).  PIO_GEMM_TILE=128|256 forces one (benchmarks).
     {

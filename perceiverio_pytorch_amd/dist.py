@@ -48,3 +48,39 @@ def all_gather_rows(local: torch.Tensor, total_rows: Optional[int] = None, group
     out = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(out, pad, group=group)
     return torch.cat([o[: hi - lo] for o, (lo, hi) in zip(out, sizes)], dim=0)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# query-dimension sharding, for batches smaller than the world (optical flow: B = 1, Q = 182 528 decoder queries).
+# Decoder query rows are mutually independent (each row's softmax runs over the latents only: reference
+# perceiver_io/transformer_primitives.py:138-166, perceiver.py:166-180), so rank r decodes rows [lo_r, hi_r) of the
+# query array against the (replicated, cheap) latents and the [B, Q/W, C] blocks are all-gathered along dim 1.
+# ---------------------------------------------------------------------------------------------------------------
+def shard_queries(query: torch.Tensor, rank: Optional[int] = None, world: Optional[int] = None,
+                  query_mask: Optional[torch.Tensor] = None):
+    """This rank's rows [lo, hi) of a [B, Q, C] query array (a view) and of its optional [B, Q] mask."""
+    if world is None:
+        world = dist.get_world_size() if dist.is_initialized() else 1
+    if rank is None:
+        rank = dist.get_rank() if dist.is_initialized() else 0
+    lo, hi = shard_bounds(query.shape[1], rank, world)
+    return query[:, lo:hi], (query_mask[:, lo:hi] if query_mask is not None else None)
+
+
+def all_gather_queries(local: torch.Tensor, total_queries: int, group=None) -> torch.Tensor:
+    """Concatenate every rank's [B, q_r, C] block along dim 1 in rank order (ragged shards padded and trimmed)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return local
+    rows_first = local.transpose(0, 1).contiguous()                   # [q_r, B, C]: the sharded axis leads
+    return all_gather_rows(rows_first, total_rows=total_queries, group=group).transpose(0, 1).contiguous()
+
+
+def decode_query_sharded(decode, query: torch.Tensor, latents: torch.Tensor,
+                         query_mask: Optional[torch.Tensor] = None, rank: Optional[int] = None,
+                         world: Optional[int] = None, group=None) -> torch.Tensor:
+    """`decode(query_rows, latents, query_mask=rows_of_mask)` on this rank's query rows, then the all-gather along
+    the query axis: every rank returns the full [B, Q, C_out].  `decode` is PerceiverDecoder.forward in the product
+    path (PerceiverIO.forward(query_shard=...), bench.py --config flow) and any row-independent function in tests."""
+    q_local, m_local = shard_queries(query, rank, world, query_mask)
+    y_local = decode(q_local, latents, query_mask=m_local)
+    return all_gather_queries(y_local, query.shape[1], group=group)

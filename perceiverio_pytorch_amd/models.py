@@ -106,12 +106,17 @@ class FlowPerceiver(nn.Module):
 
     def __init__(self, img_size: Sequence[int] = (368, 496), flow_scale_factor: int = 20 / 100,
                  num_latents: int = 2048, num_latent_channels=512, num_self_attends_per_block: int = 24,
-                 num_blocks: int = 1, mixed_precision: bool = False,
-                 precision_policy: str = DEFAULT_POLICY["FlowPerceiver"]):
+                 num_blocks: int = 1, mixed_precision: bool = False, precision_policy: str = None):
         super().__init__()
+        # The reference wraps the forward in torch.cuda.amp.autocast(enabled=mixed_precision) (flow_perceiver.py:14,
+        # 129): fp16 matmul operands, fp32 accumulation -- that is this library's single-sweep `fp16` policy.  An
+        # explicit precision_policy wins; otherwise mixed_precision=False keeps the validated class default.
+        if precision_policy is None:
+            precision_policy = "fp16" if mixed_precision else DEFAULT_POLICY["FlowPerceiver"]
         self.precision_policy = precision_policy
+        self.mixed_precision = mixed_precision
         self._flow_scale_factor = flow_scale_factor
-        self.mixed_precision = mixed_precision    # kept for signature parity: precision is set by the policy here
+        self.query_shard = None      # (rank, world): decode this rank's query rows only + all-gather (dist.py)
         prep = ImagePreprocessor(img_size=img_size, input_channels=3 * 3 ** 2, prep_type="patches",
                                  spatial_downsample=1, temporal_downsample=2, conv_after_patching=True,
                                  num_channels=64, n_extra_pos_mlp=0, position_encoding_type=PosEncodingType.FOURIER,
@@ -145,7 +150,7 @@ class FlowPerceiver(nn.Module):
 
     def _predict_patch(self, patch):
         with precision(self.precision_policy):
-            return self.perceiver(patches_for_flow(patch).movedim(-1, -3))
+            return self.perceiver(patches_for_flow(patch).movedim(-1, -3), query_shard=self.query_shard)
 
     def forward(self, image1: torch.Tensor, image2: torch.Tensor, test_mode: bool = False, min_overlap: int = 20):
         h, w = image1.shape[2], image1.shape[3]

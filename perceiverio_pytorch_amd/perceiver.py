@@ -70,10 +70,11 @@ class PerceiverEncoder(nn.Module):
         nsplit = R.batch_streams()
         if nsplit <= 1 or B < 2 * nsplit or B % nsplit:
             ws = R.workspace(dev, lib.pio_encoder_workspace_bytes(cross, layers, Lyr, B, M, N))
-            L.check(lib.pio_encoder_fwd(cross, layers, Lyr, self._num_blocks, R.tensor3(x), R.tensor3(z0), im_ptr,
-                                        out.data_ptr(), ws.data_ptr(), ws.numel(), R.stream_ptr(dev)),
-                    "pio_encoder_fwd")
-            return out
+            with R.on_device(dev):
+                L.check(lib.pio_encoder_fwd(cross, layers, Lyr, self._num_blocks, R.tensor3(x), R.tensor3(z0), im_ptr,
+                                            out.data_ptr(), ws.data_ptr(), ws.numel(), R.stream_ptr(dev)),
+                        "pio_encoder_fwd")
+            return R.forward_only(out, inputs, latents, *self.parameters())
         # Samples are independent: run `nsplit` batch slices as independent kernel chains on side streams so that
         # one chain's fill / drain / HBM-bound kernels overlap the other's MFMA-bound ones (each slice still fills
         # >= half of the CUs).  Every slice has its own workspace; the current stream waits for all of them.
@@ -81,7 +82,7 @@ class PerceiverEncoder(nn.Module):
         bs = B // nsplit
         for i, side in enumerate(R.side_streams(dev, nsplit)):
             side.wait_stream(cur)
-            with torch.cuda.stream(side):
+            with R.on_device(dev), torch.cuda.stream(side):
                 xs, zs = x[i * bs:(i + 1) * bs], z0[i * bs:(i + 1) * bs]
                 ws = R.workspace(dev, lib.pio_encoder_workspace_bytes(cross, layers, Lyr, bs, M, N))
                 mp = im_ptr + i * bs * M if im_ptr is not None else None
@@ -92,7 +93,7 @@ class PerceiverEncoder(nn.Module):
         for t in (x, z0, out):
             for side in R.side_streams(dev, nsplit):
                 t.record_stream(side)
-        return out
+        return R.forward_only(out, inputs, latents, *self.parameters())
 
 
 class PerceiverDecoder(nn.Module):
@@ -130,6 +131,10 @@ class PerceiverDecoder(nn.Module):
         self._final_cache = None
         return super()._apply(fn, *a, **k)
 
+    def _load_from_state_dict(self, *a, **k):
+        self._final_cache = None
+        return super()._load_from_state_dict(*a, **k)
+
     def _final_desc(self):
         key = R.param_key(self.final_layer.weight, self.final_layer.bias)
         if self._final_cache is None or self._final_cache[0] != key:
@@ -152,9 +157,10 @@ class PerceiverDecoder(nn.Module):
         out = torch.empty((B, Q, out_ch), dtype=torch.float32, device=dev)
         fin_ptr = C.byref(fin.desc) if fin is not None else None
         ws = R.workspace(dev, lib.pio_decoder_workspace_bytes(cross, fin_ptr, B, Q, N))
-        L.check(lib.pio_decoder_fwd(cross, fin_ptr, out_ch, R.tensor3(q), R.tensor3(z), qm_ptr, out.data_ptr(),
-                                    ws.data_ptr(), ws.numel(), R.stream_ptr(dev)), "pio_decoder_fwd")
-        return out
+        with R.on_device(dev):
+            L.check(lib.pio_decoder_fwd(cross, fin_ptr, out_ch, R.tensor3(q), R.tensor3(z), qm_ptr, out.data_ptr(),
+                                        ws.data_ptr(), ws.numel(), R.stream_ptr(dev)), "pio_decoder_fwd")
+        return R.forward_only(out, query, latents, *self.parameters())
 
 
 # ==================================================================================================
@@ -304,14 +310,22 @@ class PerceiverIO(nn.Module):
             return next(iter(queries.values())), sizes        # keeps a broadcast table a stride-0 view
         return torch.cat([queries[m] for m in sorted(queries.keys())], dim=1), sizes
 
-    def forward(self, inputs, *, subsampled_output_points=None, pos=None, input_mask=None, query_mask=None):
+    def forward(self, inputs, *, subsampled_output_points=None, pos=None, input_mask=None, query_mask=None,
+                query_shard=None):
+        """Reference signature (perceiver.py:287-288) plus `query_shard=(rank, world)`: decode only this rank's slice
+        of the query rows and all-gather the result along the query axis (dist.decode_query_sharded) -- the
+        multi-GPU form for batches smaller than the world (optical flow).  Needs an initialised process group."""
         if type(inputs) is torch.Tensor:
             inputs = {"__default": inputs}
         x, sizes, without_pos = self._multi_preprocessor(inputs, pos=pos)
         latents0 = self._encoder.latents(x)
         query, query_sizes = self.decoder_query(x, sizes, without_pos, subsampled_points=subsampled_output_points)
         latents = self._encoder(x, latents0, input_mask=input_mask)
-        outputs = self._decoder(query, latents, query_mask=query_mask)
+        if query_shard is not None:
+            from .dist import decode_query_sharded
+            outputs = decode_query_sharded(self._decoder, query, latents, query_mask, *query_shard)
+        else:
+            outputs = self._decoder(query, latents, query_mask=query_mask)
         if self._output_postprocessors:
             per_mod = restructure(query_sizes, outputs)
             outputs = {m: post(per_mod[m], pos=None, modality_sizes=None)

@@ -234,9 +234,64 @@ class PackedStack:
                              self.n, self.k)
 
 
+def _version_of(p: torch.Tensor) -> int:
+    # (tensors created or moved under torch.inference_mode() do not track a version counter)
+    return 0 if p.is_inference() else p._version
+
+
 def param_key(*params) -> tuple:
-    """Cache key that changes whenever a parameter is rebound, moved or modified in place."""
-    return tuple((p.data_ptr(), p._version, str(p.device)) if p is not None else None for p in params) + (_policy,)
+    """Cache key that changes whenever a parameter is rebound, moved or modified in place through autograd-visible
+    ops.  Writes through ``p.data`` (``p.data.copy_()``, some checkpoint loaders) do NOT bump the version counter:
+    ``load_state_dict`` is covered by a hook of the modules; after any other raw write call
+    ``invalidate_packed_weights(module)``."""
+    return tuple((p.data_ptr(), _version_of(p), str(p.device)) if p is not None else None for p in params) + (_policy,)
+
+
+def invalidate_packed_weights(module: torch.nn.Module) -> None:
+    """Drop every packed / folded weight image cached under ``module`` (they are rebuilt on the next forward)."""
+    for m in module.modules():
+        if hasattr(m, "_pio_cache"):
+            m._pio_cache = None
+        if hasattr(m, "_final_cache"):
+            m._final_cache = None
+
+
+class _ForwardOnly(torch.autograd.Function):
+    """Identity whose backward raises: the HIP path has no autograd.  Outputs of the HIP modules are fresh buffers
+    without a grad_fn, so without this a ``loss.backward()`` would silently skip every encoder / decoder parameter."""
+
+    @staticmethod
+    def forward(ctx, out, *deps):
+        return out.view_as(out)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        raise NotImplementedError("perceiverio_pytorch_amd is a forward / inference path: there is no backward "
+                                  "through the HIP kernels (run under torch.inference_mode() or torch.no_grad())")
+
+
+def forward_only(out: torch.Tensor, *deps) -> torch.Tensor:
+    """Tie `out` to the tensors it was computed from when autograd is recording, with a backward that raises."""
+    if torch.is_grad_enabled():
+        live = [t for t in deps if isinstance(t, torch.Tensor) and t.requires_grad]
+        if live:
+            return _ForwardOnly.apply(out, *live)
+    return out
+
+
+class on_device:
+    """Make the tensor's GPU the current HIP device around a C call: the library launches on the given stream, but
+    hipGetLastError, the architecture check and the cached CU count consult the CURRENT device."""
+
+    def __init__(self, device: torch.device):
+        self._ctx = torch.cuda.device(device)
+
+    def __enter__(self):
+        self._ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        return self._ctx.__exit__(*exc)
 
 
 def layernorm_desc(ln: torch.nn.LayerNorm, keep: list) -> L.LayerNorm:

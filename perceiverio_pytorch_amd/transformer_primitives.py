@@ -81,6 +81,10 @@ class _HipModule(nn.Module):
         self._pio_cache = None
         return super()._apply(fn, *a, **k)
 
+    def _load_from_state_dict(self, *a, **k):   # load_state_dict copies through .data on some paths: repack
+        self._pio_cache = None
+        return super()._load_from_state_dict(*a, **k)
+
 
 # ==================================================================================================
 # Attention (reference :18-180)
@@ -181,10 +185,12 @@ class Attention(_HipModule):
         nbytes = lib.pio_attention_workspace_bytes(d, B, Tq, Tk)
         ws = R.workspace(dev, nbytes)
         tq, tk, tv = R.tensor3(xq), R.tensor3(xk), R.tensor3(xv)
-        L.check(lib.pio_attention_fwd(d, tq, tk, tv, None, None, fm_ptr,
-                                      bias_t.data_ptr() if bias_t is not None else None, out.data_ptr(),
-                                      probs.data_ptr() if probs is not None else None, ws.data_ptr(), ws.numel(),
-                                      R.stream_ptr(dev)), "pio_attention_fwd")
+        with R.on_device(dev):
+            L.check(lib.pio_attention_fwd(d, tq, tk, tv, None, None, fm_ptr,
+                                          bias_t.data_ptr() if bias_t is not None else None, out.data_ptr(),
+                                          probs.data_ptr() if probs is not None else None, ws.data_ptr(),
+                                          ws.numel(), R.stream_ptr(dev)), "pio_attention_fwd")
+        out = R.forward_only(out, inputs_q, inputs_k, inputs_v, *self._params())
         if return_matrix:
             return probs, out
         return out
@@ -234,8 +240,10 @@ class MLP(_HipModule):
         out = torch.empty(x3.shape[:2] + (self.fc2.out_features,), dtype=torch.float32, device=dev)
         rows = x3.shape[0] * x3.shape[1]
         ws = R.workspace(dev, lib.pio_mlp_workspace_bytes(d, rows))
-        L.check(lib.pio_mlp_fwd(d, R.tensor3(x3), out.data_ptr(), ws.data_ptr(), ws.numel(), R.stream_ptr(dev)),
-                "pio_mlp_fwd")
+        with R.on_device(dev):
+            L.check(lib.pio_mlp_fwd(d, R.tensor3(x3), out.data_ptr(), ws.data_ptr(), ws.numel(), R.stream_ptr(dev)),
+                    "pio_mlp_fwd")
+        out = R.forward_only(out, x, *self._params())
         return out.reshape(shape[:-1] + (self.fc2.out_features,))
 
 
@@ -327,10 +335,12 @@ class SelfAttention(_HipModule):
         out = torch.empty((B, N, D), dtype=torch.float32, device=dev)
         probs = torch.empty((B, H, N, N), dtype=torch.float32, device=dev) if return_matrix else None
         ws = R.workspace(dev, lib.pio_self_attention_workspace_bytes(d, B, N))
-        L.check(lib.pio_self_attention_fwd(d, R.tensor3(x), None, None, fm_ptr,
-                                           bias_t.data_ptr() if bias_t is not None else None, out.data_ptr(),
-                                           probs.data_ptr() if probs is not None else None, ws.data_ptr(),
-                                           ws.numel(), R.stream_ptr(dev)), "pio_self_attention_fwd")
+        with R.on_device(dev):
+            L.check(lib.pio_self_attention_fwd(d, R.tensor3(x), None, None, fm_ptr,
+                                               bias_t.data_ptr() if bias_t is not None else None, out.data_ptr(),
+                                               probs.data_ptr() if probs is not None else None, ws.data_ptr(),
+                                               ws.numel(), R.stream_ptr(dev)), "pio_self_attention_fwd")
+        out = R.forward_only(out, inputs, *self._params())
         if return_matrix:
             return probs, out
         return out
@@ -404,10 +414,12 @@ class CrossAttention(_HipModule):
         out = torch.empty((B, Tq, Cq), dtype=torch.float32, device=dev)
         probs = torch.empty((B, H, Tq, Tk), dtype=torch.float32, device=dev) if return_matrix else None
         ws = R.workspace(dev, lib.pio_cross_attention_workspace_bytes(d, B, Tq, Tk))
-        L.check(lib.pio_cross_attention_fwd(d, R.tensor3(xq), R.tensor3(xkv), None, None, fm_ptr,
-                                            bias_t.data_ptr() if bias_t is not None else None, out.data_ptr(),
-                                            probs.data_ptr() if probs is not None else None, ws.data_ptr(),
-                                            ws.numel(), R.stream_ptr(dev)), "pio_cross_attention_fwd")
+        with R.on_device(dev):
+            L.check(lib.pio_cross_attention_fwd(d, R.tensor3(xq), R.tensor3(xkv), None, None, fm_ptr,
+                                                bias_t.data_ptr() if bias_t is not None else None, out.data_ptr(),
+                                                probs.data_ptr() if probs is not None else None, ws.data_ptr(),
+                                                ws.numel(), R.stream_ptr(dev)), "pio_cross_attention_fwd")
+        out = R.forward_only(out, inputs_q, inputs_kv, *self._params())
         if return_matrix:
             return probs, out
         return out

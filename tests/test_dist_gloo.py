@@ -59,3 +59,48 @@ def test_shard_bounds_cover_exactly():
             assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
     with pytest.raises(ValueError):
         shard_bounds(4, 2, 2)
+
+
+# ---- query-dimension sharding (B < world: optical flow) -- the same dist.decode_query_sharded that
+# ---- PerceiverIO.forward(query_shard=...) and bench.py --config flow call, with a row-independent stand-in decoder
+def _decode_stub(query, latents, query_mask=None):
+    y = query * 3.0 + latents.sum(dim=(1, 2))[:, None, None]
+    if query_mask is not None:
+        y = torch.where(query_mask[:, :, None], y, torch.full_like(y, -7.0))
+    return y
+
+
+def _qworker(rank, world, port, total_q, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from perceiverio_pytorch_amd.dist import decode_query_sharded, shard_queries
+    B, C = 1, 6
+    query = torch.arange(B * total_q * C, dtype=torch.float32).reshape(B, total_q, C)
+    latents = torch.ones(B, 4, 3)
+    mask = (torch.arange(total_q) % 3 != 0)[None].expand(B, total_q)
+    mine, _ = shard_queries(query)
+    out = decode_query_sharded(_decode_stub, query, latents, mask)      # rank / world from the process group
+    q.put((rank, mine.shape[1], out.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("total_q", [64, 13])
+def test_query_shard_and_allgather_world2(total_q):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_qworker, args=(r, 2, port, total_q, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    query = torch.arange(total_q * 6, dtype=torch.float32).reshape(1, total_q, 6)
+    mask = (torch.arange(total_q) % 3 != 0)[None]
+    full = _decode_stub(query, torch.ones(1, 4, 3), mask).numpy()
+    assert sum(r[1] for r in res) == total_q
+    for _, _, out in res:
+        assert out.shape == full.shape and np.array_equal(out, full)

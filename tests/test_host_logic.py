@@ -132,3 +132,47 @@ def test_perceiver_io_constructor_surface():
     assert "_output_queries.__default._position_encoding.pos_embs" in keys
     assert m.state_dict()["padding_embeddings.__default.pos_embs"].shape == (1, 0)
     assert len(keys) == 73
+
+
+def test_backward_through_the_hip_path_raises():
+    """Outputs of the HIP modules are tied to their inputs / parameters with a backward that raises, so a training
+    step cannot silently skip the encoder / decoder weights (runtime.forward_only)."""
+    from perceiverio_pytorch_amd import runtime as R
+    w = torch.nn.Parameter(torch.ones(3))
+    x = torch.zeros(2, 3)
+    out = torch.empty(2, 3).fill_(1.0)              # what a HIP forward returns: a fresh buffer, no grad_fn
+    y = R.forward_only(out, x, w)
+    assert y.requires_grad and torch.equal(y, out)
+    with pytest.raises(NotImplementedError, match="forward / inference"):
+        y.sum().backward()
+    with torch.no_grad():
+        assert R.forward_only(out, x, w) is out     # nothing recorded when autograd is off
+    with torch.inference_mode():
+        assert R.forward_only(out, x, w) is out
+    assert R.forward_only(out, x, w.detach()) is out
+
+
+def test_packed_weight_cache_invalidation_hooks():
+    from perceiverio_pytorch_amd import invalidate_packed_weights, runtime as R
+    from perceiverio_pytorch_amd.perceiver import PerceiverDecoder
+    from perceiverio_pytorch_amd.transformer_primitives import MLP
+    m = MLP(8, widening_factor=1)
+    m._pio_cache = ("stale", None, None)
+    m.load_state_dict(m.state_dict())               # load_state_dict drops the packed images
+    assert m._pio_cache is None
+    d = PerceiverDecoder(8, 4, num_latent_channels=8)
+    d._final_cache = ("stale", None)
+    d.decoding_cross_attn.mlp._pio_cache = ("stale", None, None)
+    invalidate_packed_weights(d)
+    assert d._final_cache is None and d.decoding_cross_attn.mlp._pio_cache is None
+    with torch.inference_mode():
+        p = torch.nn.Parameter(torch.ones(2))
+        assert R.param_key(p)[0][1] == 0            # no version counter under inference_mode: must not raise
+
+
+def test_flow_mixed_precision_flag_is_honoured():
+    from perceiverio_pytorch_amd import models as M
+    kw = dict(img_size=(16, 16), num_latents=8, num_latent_channels=32, num_self_attends_per_block=1)
+    assert M.FlowPerceiver(**kw).precision_policy == M.DEFAULT_POLICY["FlowPerceiver"]
+    assert M.FlowPerceiver(mixed_precision=True, **kw).precision_policy == "fp16"   # autocast(fp16) analogue
+    assert M.FlowPerceiver(mixed_precision=True, precision_policy="fp16x2w", **kw).precision_policy == "fp16x2w"

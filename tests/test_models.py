@@ -4,7 +4,7 @@ import pytest
 import torch
 
 import perceiver_oracle as O
-from cases import MODEL_CASES, gen_state_dict, model_inputs
+from cases import MODEL_CASES, gen_state_dict, model_inputs, model_seed
 from _golden import load
 
 TOL = 1e-3
@@ -41,8 +41,8 @@ def test_state_dict_layout_equals_reference(name):
     assert mine == ref
 
 
-def _load_generated(model, g, dev):
-    params = gen_state_dict(spec_of(g), 31)
+def _load_generated(model, g, dev, seed=31):
+    params = gen_state_dict(spec_of(g), seed)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
     return model.to(dev).eval()
 
@@ -57,9 +57,69 @@ def _close(y, ref, what, tol=TOL, absmax=None):
     assert rl2 <= tol and rmax <= tol, f"{what}: relL2={rl2:.3e} max/absmax={rmax:.3e}"
 
 
+B4_CASES = sorted(n for n in MODEL_CASES if n.startswith("model_classify_b4_"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("policy", ["fp16", "fp16x2s", "fp16x2w", "fp16x3"])
+@pytest.mark.parametrize("name", B4_CASES)
+def test_benchmarked_path_matches_reference(name, policy):
+    """The code path bench.py times (B*512 >= 2048 latent rows: under `fp16` the LayerNorm fold and the 16-bit-pair
+    residual stream are active) against REFERENCE logits at B = 4, three parameter / input seeds, both error figures
+    held to the north_star's 1e-3."""
+    import perceiverio_pytorch_amd as P
+    dev = torch.device("cuda:0")
+    g = load(name)
+    model = _load_generated(build(name), g, dev, model_seed(name))
+    model.precision_policy = policy
+    lib = P.lib()
+    prev = lib.pio_ln_fold_enable(1)
+    try:
+        x = torch.from_numpy(model_inputs(name)[0]).to(dev)
+        with torch.inference_mode():
+            y = model(x)
+        assert y.shape == (4, 1000)
+        _close(y, g["out"], f"{name} [{policy}, fold on]", TOL if policy != "fp16x3" else 1e-4)
+        if policy == "fp16":
+            lib.pio_ln_fold_enable(0)
+            with torch.inference_mode():
+                y0 = model(x)
+            _close(y0, g["out"], f"{name} [{policy}, fold off]", TOL)
+            assert not torch.equal(y0, y), "fold on/off gave identical logits: the fold did not engage at B=4"
+    finally:
+        lib.pio_ln_fold_enable(prev)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("policy", ["fp16x3", "fp16x2w"])
-@pytest.mark.parametrize("name", sorted(MODEL_CASES))
+def test_multimodal_full_size_chunks_match_reference(policy):
+    """BASELINE config 5 at full size (M = 52 097 x 704 single-head cross-attend, 784 x 512 latents, 6 288-row decoder
+    chunks): output chunks 0 and 127 of the reference's 128-chunk loop (multimodal_perceiver.py:146-157)."""
+    from perceiverio_pytorch_amd.runtime import precision
+    name = "model_multimodal_full"
+    dev = torch.device("cuda:0")
+    g = load(name)
+    c = MODEL_CASES[name]
+    model = _load_generated(build(name), g, dev, model_seed(name))
+    images, audio = [torch.from_numpy(a).to(dev) for a in model_inputs(name)]
+    b, t, ch, h, w = images.shape
+    ics = t * h * w // c["n_chunks"]
+    acs = audio.shape[1] // model.audio_samples_per_patch // c["n_chunks"]
+    tol = TOL if policy != "fp16x3" else 1e-4
+    with torch.inference_mode(), precision(policy):
+        for k in c["chunks"]:
+            sub = {"image": torch.arange(ics * k, ics * (k + 1)), "audio": torch.arange(acs * k, acs * (k + 1)),
+                   "label": None}
+            out = model.perceiver({"image": images, "audio": audio,
+                                   "label": torch.zeros((b, model.num_classes), device=dev)},
+                                  subsampled_output_points=sub)
+            for m in ("image", "audio", "label"):
+                _close(out[m], g[f"out_{m}_{k}"], f"{name} chunk {k} {m} [{policy}]", tol)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("policy", ["fp16x3", "fp16x2w"])
+@pytest.mark.parametrize("name", sorted(n for n in MODEL_CASES if n not in B4_CASES and n != "model_multimodal_full"))
 def test_model_outputs_match_reference(name, policy):
     import perceiverio_pytorch_amd as P
     dev = torch.device("cuda:0")

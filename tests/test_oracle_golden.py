@@ -82,3 +82,47 @@ def test_encdec_subsampled_golden(name):
     sub = y[:, g["out_rows"], :]
     assert O.rel_errors(sub, g["out"])[1] <= TOL
     assert O.rel_errors(sub, g["out64"])[1] <= 2e-5
+
+
+# ---- the torch restatement (oracle/perceiver_oracle_torch.py: what bench.py's cpu_baseline leg times) is pinned by the
+# ---- same reference goldens
+def _tt(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+@pytest.mark.parametrize("name", ATTN)
+def test_torch_oracle_attention_golden(name):
+    import perceiver_oracle_torch as OT
+    g = load(name)
+    H = int(g["meta"][5])
+    m = _mask(g)
+    y = OT.attention(OT.to_torch(params(g)), _tt(g["xq"]), _tt(g["xkv"]), _tt(g["xkv"]), H,
+                     _tt(m) if m is not None else None).numpy()
+    assert O.rel_errors(y, g["out"])[1] <= TOL
+
+
+@pytest.mark.parametrize("name", CA + SA)
+def test_torch_oracle_blocks_golden(name):
+    import perceiver_oracle_torch as OT
+    g = load(name)
+    p = OT.to_torch(params(g))
+    if name in SA:
+        y = OT.self_attention(p, _tt(g["x"]), int(g["meta"][3])).numpy()
+    else:
+        m = _mask(g)
+        y = OT.cross_attention(p, _tt(g["xq"]), _tt(g["xkv"]), int(g["meta"][5]), bool(g["meta"][6]),
+                               _tt(m) if m is not None else None).numpy()
+    assert O.rel_errors(y, g["out"])[1] <= TOL
+
+
+@pytest.mark.parametrize("name", ENCDEC_FULL + [n for n in ENCDEC_SUB if n != "encdec_imagenet_b2"])
+def test_torch_oracle_encdec_golden(name):
+    import perceiver_oracle_torch as OT
+    g = load(name)
+    cfg = ENCDEC_CASES[name]
+    p_enc, p_dec, qtab, x, im, qm = gen_encdec_inputs(name, cfg, int(g["seed"]))
+    y = OT.encode_decode(p_enc, p_dec, x, qtab, **encdec_kwargs(cfg, im, qm))
+    if name in ENCDEC_SUB:
+        y = y[:, g["out_rows"], :]
+    assert O.rel_errors(y, g["out"])[1] <= TOL
