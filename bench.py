@@ -201,11 +201,51 @@ def parity_check(name, model, params, dev, policy):
     return out
 
 
+def cpu_quota():
+    """CPUs this process may actually use at once: the cgroup CPU quota (v2 cpu.max / v1 cfs_quota_us) if one is set.
+    On a shared host the affinity mask can show every core (256) while the container's share is 16: a thread pool
+    sized by the mask then thrashes."""
+    cands = ["/sys/fs/cgroup/cpu.max"]
+    try:
+        with open("/proc/self/cgroup") as f:
+            for line in f:
+                parts = line.strip().split(":", 2)
+                if len(parts) == 3 and parts[1] == "":
+                    cands.insert(0, "/sys/fs/cgroup" + parts[2].rstrip("/") + "/cpu.max")
+    except OSError:
+        pass
+    for path in cands:
+        try:
+            with open(path) as f:
+                q, per = f.read().split()[:2]
+            if q != "max":
+                return max(1, int(round(int(q) / int(per))))
+        except (OSError, ValueError):
+            pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+            q = int(f.read())
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+            per = int(f.read())
+        if q > 0:
+            return max(1, int(round(q / per)))
+    except (OSError, ValueError):
+        pass
+    return None
+
+
 def cpu_threads():
     try:
-        return len(os.sched_getaffinity(0))
+        n = len(os.sched_getaffinity(0))
     except AttributeError:
-        return os.cpu_count() or 1
+        n = os.cpu_count() or 1
+    q = cpu_quota()
+    if q is not None:
+        return min(n, q)
+    env = os.environ.get("PIO_BENCH_CPU_THREADS")
+    if env:
+        return min(n, int(env))
+    return min(n, 16)      # no quota visible: the documented CPU share of a 1-GPU box (never the whole 256-core host)
 
 
 def cpu_model():
@@ -283,6 +323,15 @@ def numpy_baseline(params, sample_b):
     O.encode_decode(enc, dec, x, qtab, **cfg["oracle"])
     dt = time.perf_counter() - t0
     return {"value": sample_b / dt, "unit": "samples/s", "sample": f"numpy fp32 oracle, B={sample_b}, {dt:.1f} s"}
+
+
+def _limit_blas_threads(n):
+    try:
+        from threadpoolctl import threadpool_limits
+        return threadpool_limits(limits=n)
+    except Exception:  # noqa: BLE001
+        import contextlib
+        return contextlib.nullcontext()
 
 
 def main():
@@ -527,8 +576,11 @@ def main():
                                                                   "multimodal": 1}[name]
         if nb > 0:
             out["cpu_baseline"] = cpu_baseline(name, params, nb)
+            out["cpu_baseline"]["affinity_cpus"] = len(os.sched_getaffinity(0))
+            out["cpu_baseline"]["cgroup_quota_cpus"] = cpu_quota()
             if name == "imagenet":
-                out["cpu_baseline"]["numpy_port"] = numpy_baseline(params, 2)
+                with _limit_blas_threads(cpu_threads()):
+                    out["cpu_baseline"]["numpy_port"] = numpy_baseline(params, 2)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -12,7 +12,8 @@
  *   - every pointer is a DEVICE pointer owned by the caller; compute calls allocate and free nothing and
  *     keep no state between calls => they are thread-safe per (stream, workspace).  The only process-wide
  *     mutable state is opt-in tooling, none of it thread-safe: the per-launch profiler (pio_prof_*) and the
- *     two A/B switches pio_ln_fold_enable / pio_gemm_kernel_override (set them before concurrent use).
+ *     A/B switches pio_ln_fold_enable / pio_gemm_kernel_override / pio_set_cu_budget (set them before
+ *     concurrent use).
  *   - scratch memory is caller-provided: query pio_*_workspace_bytes() first.
  *   - tensors at the boundary are float32, last dimension contiguous; batch / row strides are given
  *     in ELEMENTS (a batch stride of 0 is a broadcast view, e.g. the latent table of
@@ -160,6 +161,19 @@ int pio_ln_fold_enable(int on);
  * it is legal, 3: the LayerNorm-fold producer on the two-workgroups-per-CU kernel (gemm_nt_duo).  Returns the
  * previous setting. */
 int pio_gemm_kernel_override(int which);
+
+/* --- running on a part of the chip ----------------------------------------------------------------- */
+/* A stream whose kernels run only on the CUs whose bit is set in `mask` (`words` 32-bit words; bit i = CU i / 8 of
+ * XCD i % 8 on MI355X, the layout of hipExtStreamCreateWithCUMask).  Two such streams with complementary masks run
+ * two independent kernel chains side by side: one chain's HBM-bound epilogues overlap the other's MFMA main loops
+ * (PerceiverEncoder.forward with PIO_CU_SPLIT=1 runs the two halves of a batch that way).  Destroy with
+ * pio_stream_destroy. */
+int pio_stream_create_cu_mask(void **stream, const uint32_t *mask, uint32_t words);
+int pio_stream_destroy(void *stream);
+/* Process-wide (not thread-safe): the number of CUs the persistent GEMM kernels size their grids for; 0 (default) =
+ * every CU of the device.  Set it to the population of a stream's CU mask around the calls that launch on that
+ * stream.  Returns the previous value. */
+int pio_set_cu_budget(int32_t n_cu);
 
 /* --- weight packing (one-off, after load_state_dict) ------------------------------------------ */
 /* Round a channel count up to the packing granule (8). */

@@ -94,6 +94,9 @@ SIGNATURES = {
     "pio_pad8": (_i32, [_i32]),
     "pio_gemm_kernel_override": (C.c_int, [C.c_int]),
     "pio_ln_fold_enable": (C.c_int, [C.c_int]),
+    "pio_stream_create_cu_mask": (C.c_int, [P(_vp), P(C.c_uint32), C.c_uint32]),
+    "pio_stream_destroy": (C.c_int, [_vp]),
+    "pio_set_cu_budget": (C.c_int, [_i32]),
     "pio_packed_weight_bytes": (_sz, [_i32, _i32, _i32, _i32]),
     "pio_pack_linear": (C.c_int, [_vp, _vp, _i32, _i32, _i64, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "pio_layernorm_cast": (C.c_int, [P(Tensor3), P(LayerNorm), _vp, _vp, _i32, _i32, _vp]),

@@ -124,18 +124,59 @@ static int cast_pair(const pio_tensor3_t &x, const pio_layernorm_t *ln, Pair y, 
 // ------------------------------------------------------------------------------------------------------
 // attention core on already normalised / cast 16-bit inputs
 // ------------------------------------------------------------------------------------------------------
+// Upper bound of the materialised score matrix held at once (fp32 scores + 16-bit probabilities are carved for this many
+// (batch, row) slabs): attention over more than this is run sample by sample and, inside a sample, in chunks of query
+// rows -- the optical-flow cross-attends (2048 x 182 528 scores per head: 1.5 GB fp32) never get a 1.5 GB buffer.
+static const int64_t kScoreCapBytes = 256ll << 20;
+
+struct ScoreChunks {
+    int b_chunk;  // samples per pass (>= 1)
+    int q_chunk;  // query rows per pass (== Tq unless b_chunk == 1 and one sample exceeds the cap)
+};
+static ScoreChunks score_chunks(int B, int H, int Tq, int Tk) {
+    const int64_t per_sample = (int64_t)H * Tq * (int64_t)Tk * 4;
+    ScoreChunks c{B, Tq};
+    if ((int64_t)B * per_sample <= kScoreCapBytes) return c;
+    int64_t bc = kScoreCapBytes / (per_sample > 0 ? per_sample : 1);
+    if (bc >= 1) {
+        c.b_chunk = (int)bc;
+        return c;
+    }
+    c.b_chunk = 1;
+    int64_t qc = kScoreCapBytes / ((int64_t)H * Tk * 4);
+    qc = qc / 128 * 128;
+    c.q_chunk = (int)(qc < 128 ? 128 : qc);
+    if (c.q_chunk > Tq) c.q_chunk = Tq;
+    return c;
+}
+
+// true when attention_core will take a fused (score-free) kernel for every call that passes no full mask / bias /
+// probability output: the plans of the encoder / decoder (which never pass those) then carve no score buffers at all
+static bool fused_capable(const pio_attention_t &a) {
+    return !a.act_split && (flash_supported(a.dkp, a.dvp) || xattn_supported(a.dkp, a.dvp));
+}
+
 struct AttnScratch {
     Pair q16, k16, vt16, p16, o16;
     float *scores;
-    void carve(Carver &c, const pio_attention_t &a, int Bq, int B, int Tq, int Tk) {
+    void *xpart;  // fp32 partials of the fused cross-attention's key splits
+    // need_scores = false: the caller guarantees a fused kernel (fused_capable and no full mask / bias / probabilities)
+    void carve(Carver &c, const pio_attention_t &a, int Bq, int B, int Tq, int Tk, bool need_scores = true) {
         const int64_t ldq = (int64_t)a.heads * a.dkp, ldo = (int64_t)a.heads * a.dvp, tkp = pad8(Tk);
         const bool sp = a.act_split != 0;
         q16 = take_pair(c, (size_t)Bq * Tq * ldq, sp);
         k16 = take_pair(c, (size_t)B * Tk * ldq, sp);
         vt16 = take_pair(c, (size_t)B * ldo * tkp, sp);
-        scores = (float *)c.take((size_t)B * a.heads * Tq * (int64_t)Tk * 4);
-        p16 = take_pair(c, (size_t)B * a.heads * Tq * tkp, sp);
+        scores = nullptr;
+        p16 = Pair();
+        if (need_scores) {
+            const ScoreChunks ch = score_chunks(B, a.heads, Tq, Tk);
+            scores = (float *)c.take((size_t)ch.b_chunk * a.heads * ch.q_chunk * (int64_t)Tk * 4);
+            p16 = take_pair(c, (size_t)ch.b_chunk * a.heads * ch.q_chunk * tkp, sp);
+        }
         o16 = take_pair(c, (size_t)B * Tq * ldo, sp);
+        const size_t xb = (!sp && xattn_supported(a.dkp, a.dvp)) ? xattn_partial_bytes(a.dkp, a.dvp, B, a.heads, Tq, Tk) : 0;
+        xpart = xb ? c.take(xb) : nullptr;
     }
 };
 
@@ -224,70 +265,103 @@ static int attention_core(const pio_attention_t &a, Pair xq, bool q_bcast, Pair 
         g.n_store = (int)tkp;
         PIO_TRY(gemm_nt_launch(g, s));
     }
-    // 4-6 fused (flash) when nothing needs the score matrix: no mask / bias / return_matrix, single-sweep
-    //      attention operands, supported head widths.  Otherwise the materialised path below.
-    const bool fused = !a.act_split && !kv_mask && !q_mask && !full_mask && !attention_bias && !probs_out &&
-                       flash_supported(a.dkp, a.dvp);
-    if (fused) {
+    // 4-6 fused when nothing needs the score matrix (no full mask / bias / return_matrix) and the operands are
+    //      single-sweep: the self-attention kernel (pio_flash.hip) for un-masked attention with its head widths, the
+    //      cross-attention kernel (pio_xattn.hip) for key / query mask VECTORS, wide single heads, dv != dk and few
+    //      query tiles (key splits).  Otherwise the materialised path below.
+    const bool score_free = !a.act_split && !full_mask && !attention_bias && !probs_out;
+    if (score_free && !kv_mask && !q_mask && flash_supported(a.dkp, a.dvp)) {
         PIO_TRY(flash_attention_launch(a.dtype, a.dkp, a.dvp, a.dk, w.q16.hi, k_hi, w.vt16.hi, w.o16.hi, B, H, Tq,
                                        Tk, ldq, ldq, tkp, ldo, q_bcast ? 0 : (int64_t)Tq * ldq, (int64_t)Tk * ldq,
                                        ldo * tkp, (int64_t)Tq * ldo, false, s));
         return linear_fwd(a.o, a.dtype, w.o16, (int64_t)B * Tq, out, nullptr, true, a.out, a.out, 0, res, s);
     }
-    // 4: S[b,h] = Q[b,h] K[b,h]^T (transformer_primitives.py:138), fp32 scores
-    {
-        pio_gemm_t g = gemm_defaults(a.dtype);
-        g.A = w.q16.hi;
-        g.A_lo = w.q16.lo;
-        g.B = k_hi;
-        g.B_lo = k_lo;
-        g.C = w.scores;
-        g.M = Tq;
-        g.N = Tk;
-        g.K = a.dkp;
-        g.lda = ldq;
-        g.ldb = ldq;
-        g.ldc = Tk;
-        g.batch = B * H;
-        g.nh = H;
-        g.sAb = q_bcast ? 0 : (int64_t)Tq * ldq;
-        g.sAh = a.dkp;
-        g.sBb = (int64_t)Tk * ldq;
-        g.sBh = a.dkp;
-        g.sCb = (int64_t)H * Tq * Tk;
-        g.sCh = (int64_t)Tq * Tk;
-        g.out_f32 = 1;
-        g.n_store = Tk;
-        PIO_TRY(gemm_nt_launch(g, s));
+    if (score_free && xattn_supported(a.dkp, a.dvp)) {
+        PIO_TRY(xattn_launch(a.dtype, a.dkp, a.dvp, a.dk, w.q16.hi, k_hi, w.vt16.hi, w.o16.hi, B, H, Tq, Tk, ldq, ldq,
+                             tkp, ldo, q_bcast ? 0 : (int64_t)Tq * ldq, (int64_t)Tk * ldq, ldo * tkp, (int64_t)Tq * ldo,
+                             kv_mask, q_mask, w.xpart, s));
+        return linear_fwd(a.o, a.dtype, w.o16, (int64_t)B * Tq, out, nullptr, true, a.out, a.out, 0, res, s);
     }
-    // 5: bias, scale, mask, softmax, wipe (transformer_primitives.py:143-158, 168-175)
-    PIO_TRY(softmax_rows_launch(w.scores, Tk, w.p16.hi, w.p16.lo, tkp, B, H, Tq, Tk, 1.0f / sqrtf((float)a.dk),
-                                kv_mask, q_mask, full_mask, attention_bias, a.dtype, probs_out, s));
-    // 6: O[b,:,h] = P[b,h] V[b,h] (transformer_primitives.py:163-166), heads merged by the store layout
-    {
-        pio_gemm_t g = gemm_defaults(a.dtype);
-        g.A = w.p16.hi;
-        g.A_lo = w.p16.lo;
-        g.B = w.vt16.hi;
-        g.B_lo = w.vt16.lo;
-        g.C = w.o16.hi;
-        g.C_lo = w.o16.lo;
-        g.M = Tq;
-        g.N = a.dvp;
-        g.K = (int)tkp;
-        g.lda = tkp;
-        g.ldb = tkp;
-        g.ldc = ldo;
-        g.batch = B * H;
-        g.nh = H;
-        g.sAb = (int64_t)H * Tq * tkp;
-        g.sAh = (int64_t)Tq * tkp;
-        g.sBb = ldo * tkp;
-        g.sBh = (int64_t)a.dvp * tkp;
-        g.sCb = (int64_t)Tq * ldo;
-        g.sCh = a.dvp;
-        g.n_store = a.dvp;
-        PIO_TRY(gemm_nt_launch(g, s));
+    if (!w.scores) return PIO_E_WORKSPACE;  // (the plan promised a fused kernel)
+    // Materialised path, in passes of (b_chunk samples) x (q_chunk query rows) so that the score matrix held at once
+    // stays below kScoreCapBytes.  Row chunks inside a sample only happen with b_chunk == 1 (mask pointers then move
+    // with the sample and the row).
+    const ScoreChunks ch = score_chunks(B, H, Tq, Tk);
+    if ((full_mask || attention_bias || probs_out) && (ch.b_chunk != B || ch.q_chunk != Tq)) {
+        // full masks / biases / probability outputs are [B,H,Tq,Tk]-sized themselves: callers that pass them have
+        // the memory; run them in one pass per sample
+        if (ch.q_chunk != Tq) return PIO_E_WORKSPACE;
+    }
+    for (int b0 = 0; b0 < B; b0 += ch.b_chunk) {
+        const int nb = b0 + ch.b_chunk <= B ? ch.b_chunk : B - b0;
+        for (int r0 = 0; r0 < Tq; r0 += ch.q_chunk) {
+            const int nr = r0 + ch.q_chunk <= Tq ? ch.q_chunk : Tq - r0;
+            const int64_t qoff = (q_bcast ? 0 : (int64_t)b0 * Tq * ldq) + (int64_t)r0 * ldq;
+            const int64_t koff = (int64_t)b0 * Tk * ldq;
+            // 4: S[b,h] = Q[b,h] K[b,h]^T (transformer_primitives.py:138), fp32 scores
+            {
+                pio_gemm_t g = gemm_defaults(a.dtype);
+                g.A = (const char *)w.q16.hi + qoff * 2;
+                g.A_lo = w.q16.lo ? (const char *)w.q16.lo + qoff * 2 : nullptr;
+                g.B = (const char *)k_hi + koff * 2;
+                g.B_lo = k_lo ? (const char *)k_lo + koff * 2 : nullptr;
+                g.C = w.scores;
+                g.M = nr;
+                g.N = Tk;
+                g.K = a.dkp;
+                g.lda = ldq;
+                g.ldb = ldq;
+                g.ldc = Tk;
+                g.batch = nb * H;
+                g.nh = H;
+                g.sAb = q_bcast ? 0 : (int64_t)Tq * ldq;
+                g.sAh = a.dkp;
+                g.sBb = (int64_t)Tk * ldq;
+                g.sBh = a.dkp;
+                g.sCb = (int64_t)H * nr * Tk;
+                g.sCh = (int64_t)nr * Tk;
+                g.out_f32 = 1;
+                g.n_store = Tk;
+                PIO_TRY(gemm_nt_launch(g, s));
+            }
+            // 5: bias, scale, mask, softmax, wipe (transformer_primitives.py:143-158, 168-175)
+            {
+                const int64_t moff = (int64_t)b0 * H * Tq * Tk;  // (full-size operands: only with nr == Tq)
+                PIO_TRY(softmax_rows_launch(w.scores, Tk, w.p16.hi, w.p16.lo, tkp, nb, H, nr, Tk,
+                                            1.0f / sqrtf((float)a.dk), kv_mask ? kv_mask + (int64_t)b0 * Tk : nullptr,
+                                            q_mask ? q_mask + (int64_t)b0 * Tq + r0 : nullptr,
+                                            full_mask ? full_mask + (int64_t)b0 * Tq * Tk : nullptr,
+                                            attention_bias ? attention_bias + moff : nullptr, a.dtype,
+                                            probs_out ? probs_out + moff : nullptr, s));
+            }
+            // 6: O[b,:,h] = P[b,h] V[b,h] (transformer_primitives.py:163-166), heads merged by the store layout
+            {
+                const int64_t ooff = ((int64_t)b0 * Tq + r0) * ldo, voff = (int64_t)b0 * ldo * tkp;
+                pio_gemm_t g = gemm_defaults(a.dtype);
+                g.A = w.p16.hi;
+                g.A_lo = w.p16.lo;
+                g.B = (const char *)w.vt16.hi + voff * 2;
+                g.B_lo = w.vt16.lo ? (const char *)w.vt16.lo + voff * 2 : nullptr;
+                g.C = (char *)w.o16.hi + ooff * 2;
+                g.C_lo = w.o16.lo ? (char *)w.o16.lo + ooff * 2 : nullptr;
+                g.M = nr;
+                g.N = a.dvp;
+                g.K = (int)tkp;
+                g.lda = tkp;
+                g.ldb = tkp;
+                g.ldc = ldo;
+                g.batch = nb * H;
+                g.nh = H;
+                g.sAb = (int64_t)H * nr * tkp;
+                g.sAh = (int64_t)nr * tkp;
+                g.sBb = ldo * tkp;
+                g.sBh = (int64_t)a.dvp * tkp;
+                g.sCb = (int64_t)Tq * ldo;
+                g.sCh = a.dvp;
+                g.n_store = a.dvp;
+                PIO_TRY(gemm_nt_launch(g, s));
+            }
+        }
     }
     // 7: final projection (+ residual) (transformer_primitives.py:110; SelfAttention :290, CrossAttention :396-399)
     return linear_fwd(a.o, a.dtype, w.o16, (int64_t)B * Tq, out, nullptr, true, a.out, a.out, 0, res, s);
@@ -346,14 +420,16 @@ struct SelfPlan {
     // copy of x lives in x16
     void *x16b = nullptr, *lo_a = nullptr, *lo_b = nullptr;  // lo_*: x - x16 / x1 - x16b (the stream as a 16-bit pair)
     float *part_a = nullptr, *part_b = nullptr;
-    size_t carve(void *base, const pio_self_attention_t &sa, int B, int N) {
+    // lean: the caller never passes a full mask / bias / probability output (the encoder stack): no score buffers
+    // when a fused kernel covers the block
+    size_t carve(void *base, const pio_self_attention_t &sa, int B, int N, bool lean = false) {
         Carver c(base);
         const int64_t rows = (int64_t)B * N;
         const int cmax = pad8(sa.attn.q_in) > pad8(sa.mlp.in) ? pad8(sa.attn.q_in) : pad8(sa.mlp.in);
         x16 = take_pair(c, (size_t)rows * cmax, sa.attn.act_split || sa.mlp.act_split);
         h16 = take_pair(c, (size_t)rows * pad8(sa.mlp.hidden), sa.mlp.act_split != 0);
         x1 = (float *)c.take((size_t)rows * sa.attn.out * 4);
-        core.carve(c, sa.attn, B, B, N, N);
+        core.carve(c, sa.attn, B, B, N, N, !(lean && fused_capable(sa.attn)));
         if (sa.fold.qkv.w_hi && sa.fold.fc1.w_hi) {
             x16b = c.take((size_t)rows * cmax * 2);
             lo_a = c.take((size_t)rows * cmax * 2);
@@ -463,7 +539,7 @@ struct CrossPlan {
     float *x1;
     AttnScratch core;
     bool q_bcast;
-    size_t carve(void *base, const pio_cross_attention_t &ca, int B, int Tq, int Tk, bool qb) {
+    size_t carve(void *base, const pio_cross_attention_t &ca, int B, int Tq, int Tk, bool qb, bool lean = false) {
         Carver c(base);
         q_bcast = qb;
         const int Bq = qb ? 1 : B;
@@ -474,7 +550,7 @@ struct CrossPlan {
         kv16 = take_pair(c, (size_t)B * Tk * pad8(ca.attn.k_in), ca.attn.act_split != 0);
         h16 = take_pair(c, (size_t)rows * pad8(ca.mlp.hidden), ca.mlp.act_split != 0);
         x1 = (float *)c.take((size_t)rows * ca.attn.out * 4);
-        core.carve(c, ca.attn, Bq, B, Tq, Tk);
+        core.carve(c, ca.attn, Bq, B, Tq, Tk, !(lean && fused_capable(ca.attn)));
         return c.off;
     }
 };
@@ -517,7 +593,7 @@ struct DecoderPlan {
             y = (float *)c.take((size_t)rows * cross.attn.q_in * 4);
             y16 = take_pair(c, (size_t)rows * pad8(cross.attn.q_in), cross.mlp.act_split != 0);
         }
-        const size_t inner = cp.carve(base ? (char *)base + c.off : nullptr, cross, B, Q, N, qb);
+        const size_t inner = cp.carve(base ? (char *)base + c.off : nullptr, cross, B, Q, N, qb, true);
         return c.off + inner;
     }
 };
@@ -626,10 +702,10 @@ size_t pio_encoder_workspace_bytes(const pio_cross_attention_t *cross, const pio
                                    int32_t B, int32_t M, int32_t N) {
     if (!cross) return 0;
     CrossPlan cp;
-    size_t need = cp.carve(nullptr, *cross, B, N, M, false);
+    size_t need = cp.carve(nullptr, *cross, B, N, M, false, true);
     for (int l = 0; l < L; ++l) {
         SelfPlan sp;
-        const size_t n = sp.carve(nullptr, layers[l], B, N);
+        const size_t n = sp.carve(nullptr, layers[l], B, N, true);
         if (n > need) need = n;
     }
     return need;
@@ -647,7 +723,7 @@ int pio_encoder_fwd(const pio_cross_attention_t *cross, const pio_self_attention
     {
         CrossPlan cp;
         const bool qb = (latents->stride_b == 0 && B > 1);
-        cp.carve(workspace, *cross, B, N, M, qb);
+        cp.carve(workspace, *cross, B, N, M, qb, true);
         // perceiver.py:99-103: only the cross-attend is masked, with mask[b,i,j] = input_mask[b,j]
         PIO_TRY(cross_attention_run(*cross, *latents, *inputs, input_mask, nullptr, nullptr, nullptr, out, nullptr,
                                     cp, s));
@@ -657,7 +733,7 @@ int pio_encoder_fwd(const pio_cross_attention_t *cross, const pio_self_attention
     for (int blk = 0; blk < num_blocks; ++blk) {  // perceiver.py:104-106: weights shared across blocks
         for (int l = 0; l < L; ++l) {
             SelfPlan sp;
-            sp.carve(workspace, layers[l], B, N);
+            sp.carve(workspace, layers[l], B, N, true);
             const bool last = blk == num_blocks - 1 && l == L - 1;
             PIO_TRY(self_attention_run(layers[l], z, nullptr, nullptr, nullptr, nullptr, out, nullptr, sp, s, &carry,
                                        last));

@@ -33,9 +33,39 @@ ProfScope::ProfScope(int cls, double flops, double bytes, hipStream_t stream) : 
 ProfScope::~ProfScope() {
     if (idx >= 0) (void)hipEventRecord(g_prof.ev[2 * idx + 1], s);
 }
+
+// CU budget of the persistent kernels' grids (pio_set_cu_budget): 0 = every CU of the device
+static int g_cu_budget = 0;
+int cu_budget() {
+    static const int n_cu = [] {
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        return n > 0 ? n : 256;
+    }();
+    return (g_cu_budget > 0 && g_cu_budget < n_cu) ? g_cu_budget : n_cu;
+}
 }  // namespace pio
 
 extern "C" {
+
+int pio_set_cu_budget(int32_t n_cu) {
+    const int prev = g_cu_budget;
+    g_cu_budget = n_cu > 0 ? n_cu : 0;
+    return prev;
+}
+
+int pio_stream_create_cu_mask(void **stream, const uint32_t *mask, uint32_t words) {
+    if (!stream || !mask || words == 0) return PIO_E_ARG;
+    hipStream_t s = nullptr;
+    if (hipExtStreamCreateWithCUMask(&s, words, mask) != hipSuccess) return PIO_E_LAUNCH;
+    *stream = (void *)s;
+    return PIO_OK;
+}
+
+int pio_stream_destroy(void *stream) {
+    if (!stream) return PIO_E_ARG;
+    return hipStreamDestroy((hipStream_t)stream) == hipSuccess ? PIO_OK : PIO_E_LAUNCH;
+}
 
 int pio_prof_begin(int32_t max_records) {
     if (max_records <= 0) return PIO_E_ARG;

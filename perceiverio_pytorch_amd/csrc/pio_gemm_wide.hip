@@ -618,11 +618,7 @@ extern "C" int pio_debug_wide_stamps(unsigned long long *out12) {
 #endif
 
 static int wide_grid(int64_t total) {
-    static const int n_cu = [] {
-        int dev = 0, n = 256;
-        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-        return n > 0 ? n : 256;
-    }();
+    const int n_cu = cu_budget();
     int G = (int)(total < n_cu ? total : n_cu);
     if (G >= 8) G &= ~7;
     return G;

@@ -85,6 +85,10 @@ struct ProfScope {
     ~ProfScope();
 };
 
+// CUs a persistent kernel may size its grid for: the device's CU count, or the budget set with pio_set_cu_budget
+// (launches on a CU-masked stream that owns only part of the chip)
+int cu_budget();
+
 // ---- internal launchers (defined in the .hip files) ---------------------------------------------
 int gemm_nt_launch(const pio_gemm_t &g, hipStream_t s);
 int gemm_kernel_override(int which);  // 0 auto, 128, 256, 1 = streaming; returns the previous choice
@@ -103,6 +107,13 @@ bool flash_supported(int dkp, int dvp);
 int flash_attention_launch(int dtype, int dkp, int dvp, int dk_logical, const void *Q, const void *K, const void *VT,
                            void *O, int B, int H, int Tq, int Tk, int64_t ldq, int64_t ldk, int64_t ldvt, int64_t ldo,
                            int64_t sQb, int64_t sKb, int64_t sVb, int64_t sOb, bool v_rowmajor, hipStream_t s);
+// fused cross-attention (pio_xattn.hip): wide single heads, dv != dk, key / query mask vectors, key splits
+bool xattn_supported(int dkp, int dvp);
+size_t xattn_partial_bytes(int dkp, int dvp, int B, int H, int Tq, int Tk);  // fp32 partials of the key splits (0: none)
+int xattn_launch(int dtype, int dkp, int dvp, int dk_logical, const void *Q, const void *K, const void *VT, void *O,
+                 int B, int H, int Tq, int Tk, int64_t ldq, int64_t ldk, int64_t ldvt, int64_t ldo, int64_t sQb,
+                 int64_t sKb, int64_t sVb, int64_t sOb, const uint8_t *kv_mask, const uint8_t *q_mask, void *partials,
+                 hipStream_t s);
 int pack_linear_launch(const float *w, const float *bias, int out, int in, int64_t ldw, int row_heads,
                        int col_heads, void *dst_hi, void *dst_lo, float *dst_bias, int dst_row0, int k_pad,
                        int dtype, hipStream_t s);

@@ -1,0 +1,507 @@
+// Fused CROSS-attention core for gfx950: O = softmax(mask(Q K^T / sqrt(dk))) V without the score matrix in HBM, for the
+// shapes the encoder / decoder cross-attends of the shipped models have and the fused self-attention kernel
+// (pio_flash.hip) does not cover: ONE wide head (322/328, 512, 704 channels), narrow heads with dv != dk (8 x (32, 160),
+// 8 x (32, 96)), a key mask vector (encoder, perceiver.py:99-103) or a query mask vector (decoder, perceiver.py:172-175),
+// a batch-invariant Q (the latent / query table projected once), and -- when batch x heads x query tiles do not fill
+// 256 CUs (optical flow: one sample, 2048 latents against 182 528 keys) -- a split over the KEYS with a partial-softmax
+// reduction (xattn_reduce_kernel).  Replaces transformer_primitives.py:138-175 (scores, scale, mask, softmax, P.v, head
+// merge, wipe of rows without an attendable key).
+//
+// Structure (one workgroup = 4 waves = 128 query rows of one (batch, head, dv slice, key split); one wave = 32 rows):
+//   * swapped products as in pio_flash.hip: S^T = K Q^T (the softmax axis is lane-local, lanes l / l+32 hold the two
+//     halves of a query column) and O^T = V^T P^T with the S^T accumulator converted in place into the P^T operand.
+//   * Q fragments stay in registers (DKL / 4 VGPRs per lane: up to 176 for the 704-wide head), the O^T accumulator of
+//     the workgroup's dv slice too (DVS / 2 registers): one wave per SIMD for the wide heads, the whole 512-register
+//     file.  A head wider than 352 is cut into dv SLICES over workgroups (each recomputes S: 1.5x the flops at 2
+//     slices) because Q fragments + a full-width accumulator do not fit.
+//   * keys in tiles of 32: K tile [32][KP] (KP = DKL rounded up to 128 elements = whole 256-byte bank rows, 16-byte
+//     chunk c of row r stored at position (c & ~15) | ((c ^ r) & 15): conflict-free ds_read_b128) and V^T tile
+//     [DVS][32 keys] (64-byte rows, chunk c of row r at c ^ ((r >> 2) & 3): conflict-free ds_read_b128), both by LDS-DMA,
+//     double buffered, ONE barrier per tile, the next tile's pieces issued between this tile's MFMAs from per-lane
+//     source offsets computed once.
+//   * the K tile's rows are PERMUTED (bits 2 and 3 of the row index swapped) so that the eight S^T accumulator
+//     registers of a k-step are eight CONSECUTIVE keys: the matching V^T fragment is one 16-byte read, not two.
+//   * masks: the tile's key mask bytes (and the "past Tk" tail) become one ballot; a masked score is -inf, i.e. p = 0
+//     exactly as exp(-1e30 - max) is in the reference; a row that never saw an attendable key has l = 0 and is written
+//     as zeros -- the reference's "wipe" (transformer_primitives.py:168-175) -- and so is a row whose query mask is 0.
+//   * nothing is zero-filled in LDS: pad chunks of K beyond dkp meet zero Q fragments, V^T rows beyond dvp feed output
+//     rows that are never stored, keys beyond Tk have p = 0; their sources are clamped to valid (finite) data.
+#include "pio_internal.h"
+
+namespace pio {
+
+struct XattnParams {
+    const void *Q, *K, *VT;
+    void *O;
+    float *part_o;   // key split: [B*H][nsplit][Tq][dvp] un-normalised O
+    float *part_ml;  // key split: [B*H][nsplit][Tq][2]   (running max in exp2 units, row sum)
+    const uint8_t *kv_mask, *q_mask;
+    int Tq, Tk, H, nqt, nslice, nsplit, tiles_per_split, dkp, dvp;
+    int64_t ldq, ldk, ldvt, ldo, sQb, sKb, sVb, sOb;
+    float scale_log2;  // log2(e) / sqrt(dk)
+};
+
+__device__ __forceinline__ void xattn_dma16(const void *src, void *lds) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                     (__attribute__((address_space(3))) void *)lds, 16, 0, 0);
+}
+
+template <int DT, int DKL, int DVS>
+__global__ __launch_bounds__(256, (DKL <= 128 && DVS <= 160) ? 2 : 1) void xattn_kernel(const XattnParams p) {
+    typedef typename Op<DT>::T T;
+    typedef typename Op<DT>::V8 V8;
+    typedef typename Op<DT>::V4 V4;
+    constexpr int KT = 32;                                               // keys per tile
+    constexpr int KP = DKL <= 128 ? 128 : ((DKL + 127) / 128) * 128;     // LDS pitch of a K row, elements
+    constexpr int KCH = KP / 8;                                          // 16-byte chunks per K row
+    constexpr int K_TILE = KT * KP * 2, V_TILE = DVS * KT * 2;           // bytes
+    constexpr int K_PIECES = K_TILE / 1024, V_PIECES = V_TILE / 1024;    // 1-KiB LDS-DMA pieces
+    constexpr int KPW = (K_PIECES + 3) / 4, VPW = (V_PIECES + 3) / 4;    // pieces per wave
+    constexpr int NQS = DKL / 16, NDT = DVS / 32;
+    static_assert(DKL % 16 == 0 && DVS % 32 == 0 && K_TILE % 1024 == 0 && V_TILE % 1024 == 0, "tile shapes");
+    constexpr int SINK = 2 * (K_TILE + V_TILE);  // 1 KiB per wave: where DMA pieces go when there is no next tile
+    __shared__ __attribute__((aligned(16))) char smem[SINK + 4096];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r32 = lane & 31, hh = lane >> 5;
+    // 1-D grid; consecutive ids of ONE XCD (ids are dealt round-robin over the 8 XCDs) walk the query tiles and dv
+    // slices of one (batch, head, key split), which stream the same K / V^T: their re-reads hit that L2.
+    int bid = blockIdx.x;
+    const int nblk = gridDim.x;
+    if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
+    const int qt = bid % p.nqt;
+    int rest = bid / p.nqt;
+    const int ds = rest % p.nslice;
+    rest /= p.nslice;
+    const int sp = rest % p.nsplit;
+    const int bh = rest / p.nsplit;
+    const int b = bh / p.H, h = bh % p.H;
+    const int q0 = qt * 128 + wave * 32;
+    const int d0 = ds * DVS;
+
+    const T *Qg = (const T *)p.Q + b * p.sQb + (int64_t)h * p.dkp;
+    const T *Kg = (const T *)p.K + b * p.sKb + (int64_t)h * p.dkp;
+    const T *Vg = (const T *)p.VT + b * p.sVb + ((int64_t)h * p.dvp + d0) * p.ldvt;
+
+    // ---- Q fragments (B operand of S^T = K Q^T): lane holds Q[q0 + r32][16 s + 8 hh + 0..7]; zero beyond dkp
+    V8 qf[NQS];
+    {
+        int q = q0 + r32;
+        q = q < p.Tq ? q : p.Tq - 1;
+        const T *qrow = Qg + (int64_t)q * p.ldq + 8 * hh;
+        const V8 zero8 = {};
+#pragma unroll
+        for (int s = 0; s < NQS; ++s) qf[s] = (16 * s + 8 * hh < p.dkp) ? *(const V8 *)(qrow + 16 * s) : zero8;
+    }
+
+    const int ntiles = (p.Tk + KT - 1) / KT;
+    const int t_begin = sp * p.tiles_per_split;
+    int t_end = t_begin + p.tiles_per_split;
+    t_end = t_end < ntiles ? t_end : ntiles;
+
+    // ---- per-lane source offsets of this wave's DMA pieces (elements, relative to the tile's first key).  A tile
+    // that reaches past Tk (the last one) recomputes its sources with the key / column clamped instead.
+    auto k_source = [&](int pc, int k0, bool clamp) -> int64_t {  // element offset from Kg
+        const int ci = pc * 64 + lane;               // LDS chunk index inside the K tile
+        const int row = ci / KCH, pos = ci % KCH;
+        int c = (pos & ~15) | ((pos ^ row) & 15);    // the logical chunk stored at this position
+        c = c * 8 < p.dkp ? c : (p.dkp >> 3) - 1;    // pad chunks: any finite data (their Q fragment is zero)
+        int key = k0 + ((row & ~12) | ((row & 4) << 1) | ((row & 8) >> 1));  // tile row -> key: bits 2, 3 swapped
+        if (clamp) key = key < p.Tk ? key : p.Tk - 1;
+        return (int64_t)key * p.ldk + c * 8;
+    };
+    auto v_source = [&](int pc, int k0, bool clamp) -> int64_t {  // element offset from Vg
+        const int ci = pc * 64 + lane;               // LDS chunk index inside the V^T tile: 4 chunks per row
+        int row = ci >> 2;
+        int kcol = k0 + (((ci & 3) ^ ((row >> 2) & 3)) << 3);
+        row = d0 + row < p.dvp ? row : p.dvp - 1 - d0;   // rows beyond dvp: finite data, never stored
+        if (clamp) kcol = kcol + 8 <= p.ldvt ? kcol : (int)p.ldvt - 8;
+        return (int64_t)row * p.ldvt + kcol;
+    };
+    uint32_t koff[KPW], voff[VPW];   // (element offsets < 2^31: launcher)
+#pragma unroll
+    for (int i = 0; i < KPW; ++i) koff[i] = (uint32_t)k_source(wave + 4 * i, 0, false);
+#pragma unroll
+    for (int i = 0; i < VPW; ++i) voff[i] = (uint32_t)v_source(wave + 4 * i, 0, false);
+
+    // Fast path (every tile but one that reaches past Tk): piece i of the next tile = uniform tile base + the lane's
+    // precomputed 32-bit offset, issued between the MFMAs of the current tile -- ALWAYS issued, without a branch:
+    // when there is no next tile to stage this way the pieces re-read the current tile into a per-wave sink.  Slow
+    // path (the tail tile): every source is recomputed with the key / column clamped, in a rolled loop -- kept out of
+    // the unrolled main body so that none of its lane-constant address arithmetic is hoisted into registers that live
+    // across the tile loop.
+    char *stage_kb = smem + SINK + wave * 1024, *stage_vb = stage_kb;
+    int stage_step = 0;
+    const T *stage_k = Kg, *stage_v = Vg;
+    auto stage_begin = [&](int kt, int buf) {
+        stage_kb = smem + buf * (K_TILE + V_TILE) + wave * 1024;
+        stage_vb = stage_kb + K_TILE;
+        stage_step = 4096;
+        stage_k = Kg + (int64_t)kt * KT * p.ldk;
+        stage_v = Vg + kt * KT;
+    };
+    auto stage_none = [&]() {
+        stage_kb = stage_vb = smem + SINK + wave * 1024;
+        stage_step = 0;
+    };
+    auto stage_piece = [&](int i) {  // 0..KPW-1: K pieces, KPW..KPW+VPW-1: V^T pieces
+        // (the offset is made opaque so that its zero-extension is not hoisted out of the tile loop as a 64-bit
+        //  register pair per piece: "uniform base + zext(32-bit VGPR)" at the use selects the SGPR-base form of the DMA)
+        if (i < KPW) {
+            if (wave + 4 * i < K_PIECES) {
+                uint32_t &o = koff[i];
+                asm volatile("" : "+v"(o));
+                xattn_dma16((const char *)stage_k + 2 * (uint64_t)o, stage_kb + i * stage_step);
+            }
+        } else {
+            if (wave + 4 * (i - KPW) < V_PIECES) {
+                uint32_t &o = voff[i - KPW];
+                asm volatile("" : "+v"(o));
+                xattn_dma16((const char *)stage_v + 2 * (uint64_t)o, stage_vb + (i - KPW) * stage_step);
+            }
+        }
+    };
+    auto stage_slow = [&](int kt, int buf) {
+        char *kb_ = smem + buf * (K_TILE + V_TILE);
+        char *vb_ = kb_ + K_TILE;
+        const int k0 = kt * KT;
+#pragma unroll 1
+        for (int pc = wave; pc < K_PIECES; pc += 4) xattn_dma16(Kg + k_source(pc, k0, true), kb_ + pc * 1024);
+#pragma unroll 1
+        for (int pc = wave; pc < V_PIECES; pc += 4) xattn_dma16(Vg + v_source(pc, k0, true), vb_ + pc * 1024);
+    };
+    auto is_tail = [&](int kt) { return kt * KT + KT > p.Tk || kt * KT + KT > p.ldvt; };
+
+    f32x16 oacc[NDT];
+#pragma unroll
+    for (int i = 0; i < NDT; ++i)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) oacc[i][j] = 0.f;
+    float m_run = -INFINITY;  // running max in exp2 units, identical in lanes l and l + 32
+    float l_run = 0.f;        // this lane's partial row sum
+
+    // LDS read addresses.  The swizzles are XORs with a lane constant, so "base + immediate" does not apply directly;
+    // but chunk (2 s + hh) ^ r32 only depends on s through (2 s) & 15: EIGHT lane registers cover every k-step of K
+    // (the 256-byte block index s >> 3 is an immediate), two cover V^T (the d tile is an immediate).  Kept opaque so
+    // that the compiler neither re-derives one address per unrolled read (dozens of registers living across the tile
+    // loop: that spilled) nor folds them back into the loop.
+    int kaddr[8], vaddr[2];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        kaddr[e] = r32 * (KP * 2) + ((((2 * e) ^ hh ^ r32) & 15) << 4);
+        asm volatile("" : "+v"(kaddr[e]));
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+        vaddr[s2] = r32 * 64 + ((((2 * s2) | hh) ^ ((r32 >> 2) & 3)) << 4);
+        asm volatile("" : "+v"(vaddr[s2]));
+    }
+
+    if (t_begin < t_end) stage_slow(t_begin, 0);
+    for (int kt = t_begin; kt < t_end; ++kt) {
+        const int it = kt - t_begin;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kt + 1 < t_end && !is_tail(kt + 1)) {
+            stage_begin(kt + 1, (it + 1) & 1);
+        } else {
+            if (kt + 1 < t_end) stage_slow(kt + 1, (it + 1) & 1);
+            stage_none();
+        }
+        const char *kb = smem + (it & 1) * (K_TILE + V_TILE);
+        const char *vb = kb + K_TILE;
+
+        // ---- S^T = K Q^T.  Fragments are read one GROUP of k-steps ahead into a second register set (the wave is
+        // alone on its SIMD: nobody else hides its LDS latency), and scheduling barriers keep the compiler from
+        // hoisting every read of the tile to the top (which spills).  The next tile's DMA pieces ride between the MFMAs.
+        f32x16 sacc;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) sacc[j] = 0.f;
+        constexpr int SG = 4, NSG = (NQS + SG - 1) / SG;
+        V8 kf[2][SG];
+        auto k_group = [&](int g, V8 *dst) {
+#pragma unroll
+            for (int t = 0; t < SG; ++t) {
+                const int s = g * SG + t;
+                if (s < NQS) dst[t] = *(const V8 *)(kb + kaddr[s & 7] + 256 * (s >> 3));
+            }
+        };
+        k_group(0, kf[0]);
+#pragma unroll
+        for (int g = 0; g < NSG; ++g) {
+            if (g + 1 < NSG) k_group(g + 1, kf[(g + 1) & 1]);
+#pragma unroll
+            for (int t = 0; t < SG; ++t) {
+                const int s = g * SG + t;
+                if (s < NQS) {
+                    sacc = Op<DT>::mfma32(kf[g & 1][t], qf[s], sacc);
+                    if (s < KPW + VPW) stage_piece(s);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int i = NQS; i < KPW + VPW; ++i) stage_piece(i);
+        // first V^T fragments: in flight during the softmax arithmetic
+        constexpr int DG = 2, NDG = (NDT + DG - 1) / DG;
+        V8 vf[2][2 * DG];
+        auto v_group = [&](int g, V8 *dst) {
+#pragma unroll
+            for (int t = 0; t < DG; ++t) {
+                const int d = g * DG + t;
+                if (d < NDT) {
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) dst[2 * t + s2] = *(const V8 *)(vb + vaddr[s2] + 2048 * d);
+                }
+            }
+        };
+        v_group(0, vf[0]);
+        __builtin_amdgcn_sched_barrier(0);
+
+        // ---- key mask / tail: accumulator register i is key k0 + 16 (i >> 3) + 8 hh + (i & 7)
+        const int k0 = kt * KT;
+        if (p.kv_mask || k0 + KT > p.Tk) {
+            bool valid = false;
+            if (lane < KT) {
+                const int key = k0 + lane;
+                valid = key < p.Tk;
+                if (valid && p.kv_mask) valid = p.kv_mask[(int64_t)b * p.Tk + key] != 0;
+            }
+            const uint32_t bits = (uint32_t)__builtin_amdgcn_ballot_w64(valid) >> (8 * hh);
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                if (!((bits >> (16 * (i >> 3) + (i & 7))) & 1u)) sacc[i] = -INFINITY;
+        }
+        // ---- online softmax in base 2: p = exp2(s * c - m * c); a tile without an attendable key leaves m at -inf
+        float mx = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) mx = fmaxf(mx, sacc[i]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * p.scale_log2;
+        const float m_new = fmaxf(m_run, mx);
+        const float m_use = m_new == -INFINITY ? 0.f : m_new;
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);  // first attendable tile: exp2(-inf) = 0
+        m_run = m_new;
+        float psum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float e = __builtin_amdgcn_exp2f(fmaf(sacc[i], p.scale_log2, -m_use));
+            sacc[i] = e;
+            psum += e;
+        }
+        l_run = l_run * alpha + psum;
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
+#pragma unroll
+            for (int d = 0; d < NDT; ++d)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) oacc[d][j] *= alpha;
+        }
+        // ---- P^T fragments: registers 8 s .. 8 s + 7 are keys 16 s + 8 hh + 0..7 = the B operand of k-step s
+        V8 pf[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pf[s][j] = Op<DT>::from_f32(sacc[8 * s + j]);
+        // ---- O^T += V^T P^T: the A fragment of (d tile, k-step s) is ONE 16-byte chunk of V^T row 32 d + r32
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < NDG; ++g) {
+            if (g + 1 < NDG) v_group(g + 1, vf[(g + 1) & 1]);
+#pragma unroll
+            for (int t = 0; t < DG; ++t) {
+                const int d = g * DG + t;
+                if (d < NDT) {
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) oacc[d] = Op<DT>::mfma32(vf[g & 1][2 * t + s2], pf[s2], oacc[d]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    // ---- epilogue
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const int q = q0 + r32;
+    if (q >= p.Tq) return;
+    if (p.nsplit > 1) {
+        // partial result of this key split: un-normalised O and (m, l); combined by xattn_reduce_kernel
+        const int64_t prow = ((int64_t)bh * p.nsplit + sp) * p.Tq + q;
+        float *po = p.part_o + prow * p.dvp + d0;
+#pragma unroll
+        for (int d = 0; d < NDT; ++d)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int col = 32 * d + 8 * g4 + 4 * hh;
+                if (d0 + col < p.dvp) {
+                    f32x4 o;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = oacc[d][4 * g4 + j];
+                    *(f32x4 *)(po + col) = o;
+                }
+            }
+        if (ds == 0 && hh == 0) {
+            p.part_ml[prow * 2] = m_run;
+            p.part_ml[prow * 2 + 1] = l_tot;
+        }
+        return;
+    }
+    bool live = l_tot > 0.f;  // no attendable key at all: the reference wipes the row to zeros
+    if (p.q_mask) live = live && p.q_mask[(int64_t)b * p.Tq + q] != 0;
+    const float inv = live ? 1.0f / l_tot : 0.f;
+    T *orow = (T *)p.O + b * p.sOb + (int64_t)q * p.ldo + (int64_t)h * p.dvp + d0;
+#pragma unroll
+    for (int d = 0; d < NDT; ++d)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const int col = 32 * d + 8 * g4 + 4 * hh;
+            if (d0 + col < p.dvp) {
+                V4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = Op<DT>::from_f32(oacc[d][4 * g4 + j] * inv);
+                *(V4 *)(orow + col) = o;
+            }
+        }
+}
+
+// Combines the key splits of one (batch, head, query row): O = sum_s O_s 2^(m_s - M) / sum_s l_s 2^(m_s - M).
+template <int DT>
+__global__ __launch_bounds__(256) void xattn_reduce_kernel(const float *part_o, const float *part_ml, void *O,
+                                                           const uint8_t *q_mask, int H, int nsplit, int Tq, int dvp,
+                                                           int64_t ldo, int64_t sOb, int64_t total) {
+    typedef typename Op<DT>::T T;
+    typedef typename Op<DT>::V4 V4;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int d4 = dvp >> 2;
+    const int c = (int)(idx % d4) * 4;
+    const int64_t row = idx / d4;  // (bh, q)
+    const int q = (int)(row % Tq);
+    const int bh = (int)(row / Tq);
+    const int b = bh / H, h = bh % H;
+    float M = -INFINITY;
+    for (int s = 0; s < nsplit; ++s) M = fmaxf(M, part_ml[(((int64_t)bh * nsplit + s) * Tq + q) * 2]);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    float L = 0.f;
+    if (M > -INFINITY) {
+        for (int s = 0; s < nsplit; ++s) {
+            const int64_t pr = ((int64_t)bh * nsplit + s) * Tq + q;
+            const float m = part_ml[pr * 2];
+            if (m == -INFINITY) continue;  // (this split saw no attendable key: its O is zero, its l is zero)
+            const float w = __builtin_amdgcn_exp2f(m - M);
+            L += part_ml[pr * 2 + 1] * w;
+            const f32x4 o = *(const f32x4 *)(part_o + pr * dvp + c);
+            acc += o * w;
+        }
+    }
+    bool live = L > 0.f;
+    if (q_mask) live = live && q_mask[(int64_t)b * Tq + q] != 0;
+    const float inv = live ? 1.0f / L : 0.f;
+    V4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = Op<DT>::from_f32(acc[j] * inv);
+    *(V4 *)((T *)O + b * sOb + (int64_t)q * ldo + (int64_t)h * dvp + c) = o;
+}
+
+// ---- host side -------------------------------------------------------------------------------------------------
+namespace {
+struct XCfg {
+    int dkl, dvs;
+};
+// the kernel instantiations, narrowest first
+constexpr XCfg kCfgs[] = {{32, 96}, {32, 160}, {128, 128}, {352, 352}, {512, 256}, {704, 352}};
+
+const XCfg *xattn_cfg(int dkp, int dvp) {
+    for (const XCfg &c : kCfgs) {
+        if (dkp > c.dkl) continue;
+        // a head wider than one slice is cut into dv slices (each recomputes S): only where Q + O do not fit otherwise
+        const bool sliced = c.dkl >= 512;
+        if (dvp <= c.dvs || (sliced && dvp <= c.dkl)) return &c;
+    }
+    return nullptr;
+}
+}  // namespace
+
+bool xattn_supported(int dkp, int dvp) { return xattn_cfg(dkp, dvp) != nullptr; }
+
+// key splits for a launch: enough workgroups for ~2 per CU when batch x heads x query tiles x slices alone give
+// fewer than one per CU, each split keeping at least 8 key tiles
+int xattn_splits(int dkp, int dvp, int B, int H, int Tq, int Tk) {
+    const XCfg *c = xattn_cfg(dkp, dvp);
+    if (!c) return 1;
+    const int nslice = (dvp + c->dvs - 1) / c->dvs;
+    const int64_t base = (int64_t)B * H * ((Tq + 127) / 128) * nslice;
+    const int ntiles = (Tk + 31) / 32;
+    if (base >= 200 || ntiles < 16) return 1;
+    int64_t s = (512 + base - 1) / base;
+    if (s > ntiles / 8) s = ntiles / 8;
+    return s < 1 ? 1 : (int)s;
+}
+
+size_t xattn_partial_bytes(int dkp, int dvp, int B, int H, int Tq, int Tk) {
+    const int s = xattn_splits(dkp, dvp, B, H, Tq, Tk);
+    if (s <= 1) return 0;
+    return (size_t)B * H * s * Tq * ((size_t)dvp * 4 + 8) + 512;
+}
+
+int xattn_launch(int dtype, int dkp, int dvp, int dk_logical, const void *Q, const void *K, const void *VT, void *O,
+                 int B, int H, int Tq, int Tk, int64_t ldq, int64_t ldk, int64_t ldvt, int64_t ldo, int64_t sQb,
+                 int64_t sKb, int64_t sVb, int64_t sOb, const uint8_t *kv_mask, const uint8_t *q_mask, void *partials,
+                 hipStream_t s) {
+    const XCfg *c = xattn_cfg(dkp, dvp);
+    if (!c) return PIO_E_SHAPE;
+    if (!Q || !K || !VT || !O) return PIO_E_ARG;
+    if (B <= 0 || H <= 0 || Tq <= 0 || Tk <= 0 || (dkp & 7) || (dvp & 7)) return PIO_E_SHAPE;
+    if ((ldq % 8) || (ldk % 8) || (ldvt % 8) || (ldo % 4) || (sQb % 8) || (sKb % 8) || (sVb % 8) || (sOb % 4))
+        return PIO_E_ALIGN;
+    if (((uintptr_t)Q & 15) || ((uintptr_t)K & 15) || ((uintptr_t)VT & 15) || ((uintptr_t)O & 7)) return PIO_E_ALIGN;
+    if (ldvt < 8 || 32 * ldk >= (1ll << 31) || (int64_t)dvp * ldvt >= (1ll << 31)) return PIO_E_SHAPE;
+    const int nslice = (dvp + c->dvs - 1) / c->dvs;
+    const int nqt = (Tq + 127) / 128;
+    const int nsplit = xattn_splits(dkp, dvp, B, H, Tq, Tk);
+    const int ntiles = (Tk + 31) / 32;
+    const int tps = (ntiles + nsplit - 1) / nsplit;
+    if (nsplit > 1 && !partials) return PIO_E_WORKSPACE;
+    const int64_t nwg = (int64_t)B * H * nqt * nslice * nsplit;
+    if (nwg > 0x7fffffffLL) return PIO_E_SHAPE;
+    XattnParams p{};
+    p.Q = Q; p.K = K; p.VT = VT; p.O = O;
+    p.part_o = (float *)partials;
+    p.part_ml = nsplit > 1 ? (float *)partials + (size_t)B * H * nsplit * Tq * dvp : nullptr;
+    p.kv_mask = kv_mask; p.q_mask = q_mask;
+    p.Tq = Tq; p.Tk = Tk; p.H = H; p.nqt = nqt; p.nslice = nslice; p.nsplit = nsplit; p.tiles_per_split = tps;
+    p.dkp = dkp; p.dvp = dvp;
+    p.ldq = ldq; p.ldk = ldk; p.ldvt = ldvt; p.ldo = ldo; p.sQb = sQb; p.sKb = sKb; p.sVb = sVb; p.sOb = sOb;
+    p.scale_log2 = 1.4426950408889634f / sqrtf((float)dk_logical);
+    dim3 grid((unsigned)nwg, 1, 1), block(256, 1, 1);
+    {
+        // S recomputed per dv slice counts once: algorithmic flops of the reference formulation
+        ProfScope prof(PROF_FLASH, 2.0 * B * H * (double)Tq * Tk * (dkp + dvp),
+                       2.0 * B * H * ((double)Tq * (dkp + dvp) + (double)Tk * (dkp + dvp)), s);
+#define PIO_XA(DKLV, DVSV)                                                                                   \
+    do {                                                                                                     \
+        if (dtype == PIO_DT_F16) hipLaunchKernelGGL((xattn_kernel<PIO_DT_F16, DKLV, DVSV>), grid, block, 0, s, p); \
+        else hipLaunchKernelGGL((xattn_kernel<PIO_DT_BF16, DKLV, DVSV>), grid, block, 0, s, p);               \
+    } while (0)
+        if (c->dkl == 32 && c->dvs == 96) PIO_XA(32, 96);
+        else if (c->dkl == 32) PIO_XA(32, 160);
+        else if (c->dkl == 128) PIO_XA(128, 128);
+        else if (c->dkl == 352) PIO_XA(352, 352);
+        else if (c->dkl == 512) PIO_XA(512, 256);
+        else PIO_XA(704, 352);
+#undef PIO_XA
+        if (nsplit > 1) {
+            const int64_t total = (int64_t)B * H * Tq * (dvp / 4);
+            dim3 rgrid((unsigned)((total + 255) / 256), 1, 1);
+            if (dtype == PIO_DT_F16)
+                hipLaunchKernelGGL((xattn_reduce_kernel<PIO_DT_F16>), rgrid, block, 0, s, p.part_o, p.part_ml, O, q_mask,
+                                   H, nsplit, Tq, dvp, ldo, sOb, total);
+            else
+                hipLaunchKernelGGL((xattn_reduce_kernel<PIO_DT_BF16>), rgrid, block, 0, s, p.part_o, p.part_ml, O,
+                                   q_mask, H, nsplit, Tq, dvp, ldo, sOb, total);
+        }
+    }
+    return launch_status();
+}
+
+}  // namespace pio

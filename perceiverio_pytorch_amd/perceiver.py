@@ -7,6 +7,7 @@ num_self_attends_per_block stack is enqueued on the current HIP stream without r
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 import torch.nn as nn
@@ -80,16 +81,26 @@ class PerceiverEncoder(nn.Module):
         # >= half of the CUs).  Every slice has its own workspace; the current stream waits for all of them.
         cur = torch.cuda.current_stream(dev)
         bs = B // nsplit
-        for i, side in enumerate(R.side_streams(dev, nsplit)):
-            side.wait_stream(cur)
-            with R.on_device(dev), torch.cuda.stream(side):
-                xs, zs = x[i * bs:(i + 1) * bs], z0[i * bs:(i + 1) * bs]
-                ws = R.workspace(dev, lib.pio_encoder_workspace_bytes(cross, layers, Lyr, bs, M, N))
-                mp = im_ptr + i * bs * M if im_ptr is not None else None
-                L.check(lib.pio_encoder_fwd(cross, layers, Lyr, self._num_blocks, R.tensor3(xs), R.tensor3(zs), mp,
-                                            out[i * bs:(i + 1) * bs].data_ptr(), ws.data_ptr(), ws.numel(),
-                                            side.cuda_stream), "pio_encoder_fwd")
-            cur.wait_stream(side)
+        # (PIO_CU_BUDGET_ONLY=1, experiment: plain streams, but persistent grids sized for a 1/nsplit share of the chip)
+        masked = (R.cu_split() or os.environ.get("PIO_CU_BUDGET_ONLY") == "1") and 32 % nsplit == 0
+        prev_budget = lib.pio_set_cu_budget(R.cu_share(nsplit)) if masked else None
+        try:
+            sides = R.side_streams(dev, nsplit)
+            for side in sides:                   # every slice starts behind the work already queued on `cur` ...
+                side.wait_stream(cur)
+            for i, side in enumerate(sides):
+                with R.on_device(dev), torch.cuda.stream(side):
+                    xs, zs = x[i * bs:(i + 1) * bs], z0[i * bs:(i + 1) * bs]
+                    ws = R.workspace(dev, lib.pio_encoder_workspace_bytes(cross, layers, Lyr, bs, M, N))
+                    mp = im_ptr + i * bs * M if im_ptr is not None else None
+                    L.check(lib.pio_encoder_fwd(cross, layers, Lyr, self._num_blocks, R.tensor3(xs), R.tensor3(zs),
+                                                mp, out[i * bs:(i + 1) * bs].data_ptr(), ws.data_ptr(), ws.numel(),
+                                                side.cuda_stream), "pio_encoder_fwd")
+            for side in sides:                   # ... and `cur` continues behind ALL of them (a wait queued between
+                cur.wait_stream(side)            # two slices would chain them one after the other)
+        finally:
+            if masked:
+                lib.pio_set_cu_budget(prev_budget)
         for t in (x, z0, out):
             for side in R.side_streams(dev, nsplit):
                 t.record_stream(side)

@@ -159,10 +159,52 @@ def set_batch_streams(n: int) -> None:
     _nstreams = max(1, int(n))
 
 
+_cu_split = os.environ.get("PIO_CU_SPLIT", "0") == "1"
+
+
+def cu_split() -> bool:
+    return _cu_split
+
+
+def set_cu_split(on: bool) -> None:
+    """Batch-slice streams that each own a disjoint share of every XCD's CUs (pio_stream_create_cu_mask) instead of
+    plain streams: the slices' kernel chains then truly run side by side."""
+    global _cu_split
+    _cu_split = bool(on)
+    _side_streams.clear()
+
+
+def cu_share(n: int) -> int:
+    """CUs per slice when the chip is split `n` ways (MI355X: 256 CUs = 8 XCDs x 32)."""
+    return 256 // n
+
+
+def _masked_streams(device: torch.device, n: int) -> list:
+    """`n` streams with complementary CU masks: slice i owns CUs [i*32/n, (i+1)*32/n) of EVERY XCD (mask bit j is CU
+    j // 8 of XCD j % 8), so each slice keeps the round-robin dispatch over all eight L2s."""
+    import ctypes as C
+    lib = L.lib()
+    per = 32 // n
+    out = []
+    for i in range(n):
+        words = (C.c_uint32 * 8)()
+        for j in range(256):
+            if i * per <= j // 8 < (i + 1) * per:
+                words[j // 32] |= 1 << (j % 32)
+        h = C.c_void_p()
+        with torch.cuda.device(device):
+            L.check(lib.pio_stream_create_cu_mask(C.byref(h), words, 8), "pio_stream_create_cu_mask")
+        out.append(torch.cuda.ExternalStream(h.value, device=device))
+    return out
+
+
 def side_streams(device: torch.device, n: int) -> list:
-    key = (device.index if device.index is not None else torch.cuda.current_device(), n)
+    key = (device.index if device.index is not None else torch.cuda.current_device(), n, _cu_split)
     if key not in _side_streams:
-        _side_streams[key] = [torch.cuda.Stream(device=device) for _ in range(n)]
+        if _cu_split and 32 % n == 0:
+            _side_streams[key] = _masked_streams(device, n)
+        else:
+            _side_streams[key] = [torch.cuda.Stream(device=device) for _ in range(n)]
     return _side_streams[key]
 
 

@@ -400,7 +400,7 @@ def test_fused_attention_vs_oracle(dev, case, policy):
     yf = m(_t(xs, dev), _t(xkv, dev), _t(xkv, dev))
     _, ym = m(_t(xs, dev), _t(xkv, dev), _t(xkv, dev), return_matrix=True)
     # (the two round P at different points -- un-normalised vs normalised -- so they differ by ~1 ulp16 of P)
-    _assert_close(yf, ym.cpu().numpy(), TOL if policy != "bf16" else 8e-3, what=f"fused vs materialised {case} {policy}")
+    _assert_close(yf, ym.detach().cpu().numpy(), TOL if policy != "bf16" else 8e-3, what=f"fused vs materialised {case} {policy}")
     _policy("fp16x3")
     y3 = m(_t(xq, dev), _t(xkv, dev), _t(xkv, dev))
     _assert_close(y3, ref, TIGHT, what=f"materialised attention {case}")
@@ -428,7 +428,7 @@ def test_fully_fused_self_attention_qkv(dev, shape):
     _assert_close(y, ref, TOL, what=f"fused qkv {shape}")
     _policy("fp16x2s")
     y2 = m(xt, xt, xt)
-    _assert_close(y, y2.cpu().numpy(), TOL, what=f"fused qkv vs separate V^T {shape}")
+    _assert_close(y, y2.detach().cpu().numpy(), TOL, what=f"fused qkv vs separate V^T {shape}")
 
 
 @pytest.mark.parametrize("policy", POLICIES)
@@ -783,7 +783,7 @@ def test_model_layernorm_fold_b4(dev):
     import bench as Bn
     from perceiverio_pytorch_amd import _lib as L
     lib = L.lib()
-    model, _, _ = Bn.build_model(dev, "fp16")
+    model, _ = Bn.build_model("imagenet", dev, "fp16")
     x = torch.randn(4, 3, 224, 224, generator=torch.Generator().manual_seed(11)).to(dev)
     prev = lib.pio_ln_fold_enable(1)
     try:
@@ -800,3 +800,135 @@ def test_model_layernorm_fold_b4(dev):
     assert not torch.equal(y_fold, y_plain), "the fold did not run (identical results)"
     assert e_fold <= 1e-3, f"folded model relL2 {e_fold:.3e} (unfolded {e_plain:.3e})"
     assert e_fold <= 1.5 * e_plain + 1e-4, f"folded model relL2 {e_fold:.3e} vs unfolded {e_plain:.3e}"
+
+
+def test_backward_through_hip_modules_raises(dev):
+    """With autograd recording, the output of a HIP module carries a grad_fn whose backward raises -- a training step
+    cannot silently skip the encoder / decoder parameters."""
+    from perceiverio_pytorch_amd.transformer_primitives import MLP as HipMLP
+    m = HipMLP(32, widening_factor=1).to(dev)
+    x = torch.randn(2, 5, 32, device=dev)
+    with torch.enable_grad():
+        y = m(x)
+        assert y.requires_grad
+        with pytest.raises(NotImplementedError, match="forward / inference"):
+            y.sum().backward()
+    assert all(p.grad is None for p in m.parameters())
+
+
+@pytest.mark.parametrize("masked", [False, True])
+def test_encoder_batch_slice_streams_match_single_stream(dev, masked):
+    """PerceiverEncoder.forward with the batch cut into two slices on side streams (runtime.set_batch_streams(2); plain
+    streams or CU-masked ones) gives the single-stream result."""
+    from perceiverio_pytorch_amd import runtime as R
+    from perceiverio_pytorch_amd.perceiver import PerceiverEncoder
+    cfg = ENCDEC_CASES["encdec_mid"]
+    p_enc, _, _, x, _, _ = gen_encdec_inputs("encdec_mid", cfg, 21)
+    enc = PerceiverEncoder(cfg["C"], cfg["L"], cfg["blocks"], cfg["N"], cfg["D"], num_cross_attend_heads=cfg["xh"],
+                           num_self_attend_heads=cfg["sh"])
+    enc.load_state_dict(_sd(p_enc, "cpu"))
+    enc = enc.to(dev).eval()
+    xt = _t(np.concatenate([x, x[::-1]], axis=0), dev)          # B = 4: two slices of two samples
+    _policy("fp16x3")
+    try:
+        z1 = enc(xt, enc.latents(xt))
+        R.set_batch_streams(2)
+        R.set_cu_split(masked)
+        z2 = enc(xt, enc.latents(xt))
+        torch.cuda.synchronize()
+    finally:
+        R.set_batch_streams(1)
+        R.set_cu_split(False)
+    _assert_close(z2, z1.cpu().numpy(), 1e-5, what=f"2 batch-slice streams (cu masks: {masked})")
+
+
+# ----------------------------------------------------------------------------------------------------
+# fused cross-attention kernel (pio_xattn.hip): mask VECTORS, wide single heads, dv != dk, key splits
+# ----------------------------------------------------------------------------------------------------
+XATTN_CASES = [
+    # heads, dk, dv, B, Tq, Tk, mask kind, broadcast Q
+    (1, 322, 322, 2, 200, 500, "key", False),      # the 322-wide single head of the ImageNet / flow encoders, ragged
+    (1, 322, 322, 1, 512, 3136, None, True),       # ImageNet encoder shape, one sample: split over the keys
+    (1, 322, 322, 3, 512, 1000, "key_allfalse_b1", True),
+    (1, 261, 261, 1, 64, 300, None, False),        # FOURIER_POS_PIXEL width
+    (1, 512, 512, 1, 300, 2048, "query", False),   # flow / multimodal decoders: two dv slices
+    (1, 704, 704, 1, 130, 1000, "key", False),     # multimodal encoder: two dv slices of 352
+    (8, 32, 160, 2, 256, 2048, "key", True),       # language encoder
+    (8, 32, 96, 2, 700, 256, "query", False),      # language decoder
+    (4, 64, 64, 2, 100, 333, "key", False),        # generic narrow heads on the (128, 128) instantiation
+    (2, 128, 128, 1, 77, 150, "query", False),
+]
+
+
+def _attention_vector_masks(m, xq, xkv, kv_mask, q_mask, dev):
+    """Attention.forward through the C-ABI with the mask VECTORS (what PerceiverEncoder / PerceiverDecoder pass)."""
+    import perceiverio_pytorch_amd as P
+    from perceiverio_pytorch_amd import _lib as L, runtime as R
+    lib = P.lib()
+    d = m._desc()
+    B, Tq = xq.shape[0], xq.shape[1]
+    Tk = xkv.shape[1]
+    out = torch.empty((B, Tq, m.final.out_features), dtype=torch.float32, device=dev)
+    ws = R.workspace(dev, lib.pio_attention_workspace_bytes(d, B, Tq, Tk))
+    keep = []
+    kp = qp = None
+    if kv_mask is not None:
+        km = _t(kv_mask, dev).view(torch.uint8)
+        keep.append(km)
+        kp = km.data_ptr()
+    if q_mask is not None:
+        qm = _t(q_mask, dev).view(torch.uint8)
+        keep.append(qm)
+        qp = qm.data_ptr()
+    L.check(lib.pio_attention_fwd(d, R.tensor3(xq), R.tensor3(xkv), R.tensor3(xkv), kp, qp, None, None,
+                                  out.data_ptr(), None, ws.data_ptr(), ws.numel(), R.stream_ptr(dev)), "pio_attention_fwd")
+    torch.cuda.synchronize()
+    return out
+
+
+@pytest.mark.parametrize("policy", ["fp16", "fp16x2w", "bf16"])
+@pytest.mark.parametrize("case", XATTN_CASES)
+def test_fused_cross_attention_vs_oracle(dev, case, policy):
+    """Attention on the fused cross-attention kernel (mask vectors, wide heads, dv != dk, key splits) against the float64
+    oracle with the equivalent full mask, and against the materialised path of the SAME policy (full mask tensor)."""
+    from perceiverio_pytorch_amd.transformer_primitives import Attention
+    H, dk, dv, B, Tq, Tk, mk, bcast = case
+    q_in, kv_in = 64, 96
+    p = O.gen_attention("", q_in, kv_in, H * dk, H * dv, q_in, seed=dk + Tq)
+    rng = np.random.default_rng(Tk + dk)
+    xq = rng.standard_normal((1 if bcast else B, Tq, q_in)).astype(np.float32)
+    xkv = rng.standard_normal((B, Tk, kv_in)).astype(np.float32)
+    qm = km = None
+    if mk in ("key", "key_allfalse_b1"):
+        km = rng.random((B, Tk)) > 0.3
+        km[:, 0] = True
+        if mk == "key_allfalse_b1":
+            km[1, :] = False
+    elif mk == "query":
+        qm = rng.random((B, Tq)) > 0.3
+    m = Attention(q_in, kv_in, kv_in, num_heads=H, qk_out_channels=H * dk, v_out_channels=H * dv, output_channels=q_in)
+    m.load_state_dict(_sd(p, "cpu"))
+    m = m.to(dev).eval()
+    xq_full = np.broadcast_to(xq, (B, Tq, q_in))
+    mask3 = None
+    if mk is not None:
+        mask3 = O.make_cross_attention_mask(qm if qm is not None else np.ones((B, Tq), bool),
+                                            km if km is not None else np.ones((B, Tk), bool))
+    p64 = {k: a.astype(np.float64) for k, a in p.items()}
+    ref = O.attention(p64, xq_full.astype(np.float64), xkv.astype(np.float64), xkv.astype(np.float64), H, mask3)
+    xq_t = _t(xq, dev)
+    if bcast:
+        xq_t = torch.broadcast_to(xq_t, (B, Tq, q_in))          # stride-0 batch: Q is projected once
+    _policy(policy)
+    y = _attention_vector_masks(m, xq_t, _t(xkv, dev), km, qm, dev)
+    # (random toy weights on 64 / 96 input channels: operand rounding alone is ~1e-3 here -- the budget of the toy
+    #  goldens; the kernel itself is held to TOL against the materialised path of the same policy below)
+    tol = TOL if policy != "bf16" else 1e-2
+    _assert_close(y, ref, FAST_TOY_BUDGET if policy != "bf16" else 2e-2, what=f"fused cross-attention {case} {policy}")
+    if mk == "key_allfalse_b1":
+        fb = m.final.bias.detach()
+        assert torch.equal(y[1], fb[None, :].expand_as(y[1])), "sample without an attendable key must give final.bias"
+    # same policy, materialised path (a full mask tensor forces it): same operand rounding, different algorithm
+    full = _t(mask3 if mask3 is not None else np.ones((B, Tq, Tk), bool), dev)
+    ym = m(xq_t, _t(xkv, dev), _t(xkv, dev), attention_mask=full)
+    _assert_close(y, ym.detach().cpu().numpy(), tol, what=f"fused vs materialised {case} {policy}")
