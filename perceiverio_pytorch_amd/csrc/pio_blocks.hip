@@ -163,10 +163,13 @@ struct AttnScratch {
     // need_scores = false: the caller guarantees a fused kernel (fused_capable and no full mask / bias / probabilities)
     void carve(Carver &c, const pio_attention_t &a, int Bq, int B, int Tq, int Tk, bool need_scores = true) {
         const int64_t ldq = (int64_t)a.heads * a.dkp, ldo = (int64_t)a.heads * a.dvp, tkp = pad8(Tk);
+        const int64_t tkv = round_up(Tk, 32);  // V^T row pitch: whole 32-key tiles, zero padded (pio_xattn.hip)
         const bool sp = a.act_split != 0;
         q16 = take_pair(c, (size_t)Bq * Tq * ldq, sp);
-        k16 = take_pair(c, (size_t)B * Tk * ldq, sp);
-        vt16 = take_pair(c, (size_t)B * ldo * tkp, sp);
+        // (+ 32 rows: the fused cross-attention kernel reads whole 32-key tiles; the rows behind key Tk - 1 only have
+        //  to be readable -- their scores are masked by assignment)
+        k16 = take_pair(c, (size_t)(B * (int64_t)Tk + 32) * ldq, sp);
+        vt16 = take_pair(c, (size_t)B * ldo * tkv, sp);
         scores = nullptr;
         p16 = Pair();
         if (need_scores) {
@@ -198,7 +201,7 @@ static int attention_core(const pio_attention_t &a, Pair xq, bool q_bcast, Pair 
                           const LnFold *fold_out = nullptr) {
     PIO_TRY(check_attention(a));
     const int H = a.heads;
-    const int64_t hdk = (int64_t)H * a.dkp, ldo = (int64_t)H * a.dvp, tkp = pad8(Tk);
+    const int64_t hdk = (int64_t)H * a.dkp, ldo = (int64_t)H * a.dvp, tkp = pad8(Tk), tkv = round_up(Tk, 32);
     const int Bq = q_bcast ? 1 : B;
 
     // 0: the fully fused self-attention form: ONE GEMM over the stacked [q | k | v] weight image, then the fused
@@ -256,13 +259,13 @@ static int attention_core(const pio_attention_t &a, Pair xq, bool q_bcast, Pair 
         g.K = a.v.k;
         g.lda = a.v.k;
         g.ldb = a.v.k;
-        g.ldc = tkp;
+        g.ldc = tkv;
         g.batch = B;
         g.sBb = (int64_t)Tk * a.v.k;
-        g.sCb = ldo * tkp;
+        g.sCb = ldo * tkv;
         g.bias = a.v.bias;
         g.bias_mode = a.v.bias ? 2 : 0;
-        g.n_store = (int)tkp;
+        g.n_store = (int)tkv;  // columns [Tk, tkv) are written as zeros
         PIO_TRY(gemm_nt_launch(g, s));
     }
     // 4-6 fused when nothing needs the score matrix (no full mask / bias / return_matrix) and the operands are
@@ -272,13 +275,13 @@ static int attention_core(const pio_attention_t &a, Pair xq, bool q_bcast, Pair 
     const bool score_free = !a.act_split && !full_mask && !attention_bias && !probs_out;
     if (score_free && !kv_mask && !q_mask && flash_supported(a.dkp, a.dvp)) {
         PIO_TRY(flash_attention_launch(a.dtype, a.dkp, a.dvp, a.dk, w.q16.hi, k_hi, w.vt16.hi, w.o16.hi, B, H, Tq,
-                                       Tk, ldq, ldq, tkp, ldo, q_bcast ? 0 : (int64_t)Tq * ldq, (int64_t)Tk * ldq,
-                                       ldo * tkp, (int64_t)Tq * ldo, false, s));
+                                       Tk, ldq, ldq, tkv, ldo, q_bcast ? 0 : (int64_t)Tq * ldq, (int64_t)Tk * ldq,
+                                       ldo * tkv, (int64_t)Tq * ldo, false, s));
         return linear_fwd(a.o, a.dtype, w.o16, (int64_t)B * Tq, out, nullptr, true, a.out, a.out, 0, res, s);
     }
     if (score_free && xattn_supported(a.dkp, a.dvp)) {
         PIO_TRY(xattn_launch(a.dtype, a.dkp, a.dvp, a.dk, w.q16.hi, k_hi, w.vt16.hi, w.o16.hi, B, H, Tq, Tk, ldq, ldq,
-                             tkp, ldo, q_bcast ? 0 : (int64_t)Tq * ldq, (int64_t)Tk * ldq, ldo * tkp, (int64_t)Tq * ldo,
+                             tkv, ldo, q_bcast ? 0 : (int64_t)Tq * ldq, (int64_t)Tk * ldq, ldo * tkv, (int64_t)Tq * ldo,
                              kv_mask, q_mask, w.xpart, s));
         return linear_fwd(a.o, a.dtype, w.o16, (int64_t)B * Tq, out, nullptr, true, a.out, a.out, 0, res, s);
     }
@@ -336,7 +339,7 @@ static int attention_core(const pio_attention_t &a, Pair xq, bool q_bcast, Pair 
             }
             // 6: O[b,:,h] = P[b,h] V[b,h] (transformer_primitives.py:163-166), heads merged by the store layout
             {
-                const int64_t ooff = ((int64_t)b0 * Tq + r0) * ldo, voff = (int64_t)b0 * ldo * tkp;
+                const int64_t ooff = ((int64_t)b0 * Tq + r0) * ldo, voff = (int64_t)b0 * ldo * tkv;
                 pio_gemm_t g = gemm_defaults(a.dtype);
                 g.A = w.p16.hi;
                 g.A_lo = w.p16.lo;
@@ -348,14 +351,14 @@ static int attention_core(const pio_attention_t &a, Pair xq, bool q_bcast, Pair 
                 g.N = a.dvp;
                 g.K = (int)tkp;
                 g.lda = tkp;
-                g.ldb = tkp;
+                g.ldb = tkv;
                 g.ldc = ldo;
                 g.batch = nb * H;
                 g.nh = H;
                 g.sAb = (int64_t)H * nr * tkp;
                 g.sAh = (int64_t)nr * tkp;
-                g.sBb = ldo * tkp;
-                g.sBh = (int64_t)a.dvp * tkp;
+                g.sBb = ldo * tkv;
+                g.sBh = (int64_t)a.dvp * tkv;
                 g.sCb = (int64_t)Tq * ldo;
                 g.sCh = a.dvp;
                 g.n_store = a.dvp;

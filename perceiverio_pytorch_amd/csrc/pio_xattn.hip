@@ -26,16 +26,29 @@
 //     as zeros -- the reference's "wipe" (transformer_primitives.py:168-175) -- and so is a row whose query mask is 0.
 //   * nothing is zero-filled in LDS: pad chunks of K beyond dkp meet zero Q fragments, V^T rows beyond dvp feed output
 //     rows that are never stored, keys beyond Tk have p = 0; their sources are clamped to valid (finite) data.
+#include <stdlib.h>
+
+#include <type_traits>
+
 #include "pio_internal.h"
 
 namespace pio {
+
+template <int I, int N, class F>
+__device__ __forceinline__ void xa_for(F &&f) {  // compile-time loop: the index arrives as an integral_constant
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        xa_for<I + 1, N>(f);
+    }
+}
 
 struct XattnParams {
     const void *Q, *K, *VT;
     void *O;
     float *part_o;   // key split: [B*H][nsplit][Tq][dvp] un-normalised O
     float *part_ml;  // key split: [B*H][nsplit][Tq][2]   (running max in exp2 units, row sum)
-    const uint8_t *kv_mask, *q_mask;
+    const uint8_t *q_mask;
+    const uint32_t *key_bits;  // [B][ntiles]: bit j of word t = key 32 t + j is attendable (NULL: every key < Tk is)
     int Tq, Tk, H, nqt, nslice, nsplit, tiles_per_split, dkp, dvp;
     int64_t ldq, ldk, ldvt, ldo, sQb, sKb, sVb, sOb;
     float scale_log2;  // log2(e) / sqrt(dk)
@@ -46,20 +59,61 @@ __device__ __forceinline__ void xattn_dma16(const void *src, void *lds) {
                                      (__attribute__((address_space(3))) void *)lds, 16, 0, 0);
 }
 
+// MFMAs as inline assembly with their register files pinned (the pattern of pio_gemm_wide.hip).  The O^T accumulator
+// (up to 176 registers) lives in AGPRs and accumulates in place; the first (256 - |O^T|) / 4 Q fragments live in AGPRs
+// too (they are only ever MFMA operands), the rest and everything the VALU touches in the 256 architectural VGPRs.
+// Left to the register allocator the wide-head instantiations spilled Q fragments to scratch, and every reload sat in
+// the vector-memory queue behind the LDS-DMA pieces.  The compiler's hazard recogniser does not look inside an asm
+// statement: the places where a VALU instruction reads what an MFMA wrote (softmax after S^T, the epilogue) or an MFMA
+// reads an accumulator the VALU wrote (after a rescale) carry explicit s_nop padding below.
+template <int DT, bool B_IN_AGPR>
+__device__ __forceinline__ void xa_mfma_v(f32x16 &c, typename Op<DT>::V8 a, typename Op<DT>::V8 b) {  // acc in VGPRs
+    if constexpr (DT == PIO_DT_F16) {
+        if constexpr (B_IN_AGPR) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "a"(b));
+        else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+    } else {
+        if constexpr (B_IN_AGPR) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "a"(b));
+        else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+    }
+}
+template <int DT, bool B_IN_AGPR>
+__device__ __forceinline__ void xa_mfma_v0(f32x16 &c, typename Op<DT>::V8 a, typename Op<DT>::V8 b) {  // c = a b
+    if constexpr (DT == PIO_DT_F16) {
+        if constexpr (B_IN_AGPR) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=v"(c) : "v"(a), "a"(b));
+        else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=v"(c) : "v"(a), "v"(b));
+    } else {
+        if constexpr (B_IN_AGPR) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(c) : "v"(a), "a"(b));
+        else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(c) : "v"(a), "v"(b));
+    }
+}
+template <int DT>
+__device__ __forceinline__ void xa_mfma_a(f32x16 &c, typename Op<DT>::V8 a, typename Op<DT>::V8 b) {  // acc in AGPRs
+    if constexpr (DT == PIO_DT_F16) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+    else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+
 template <int DT, int DKL, int DVS>
 __global__ __launch_bounds__(256, (DKL <= 128 && DVS <= 160) ? 2 : 1) void xattn_kernel(const XattnParams p) {
     typedef typename Op<DT>::T T;
     typedef typename Op<DT>::V8 V8;
     typedef typename Op<DT>::V4 V4;
     constexpr int KT = 32;                                               // keys per tile
+    constexpr bool PIN = DKL > 128 && DKL <= 512;  // wide heads without spills: one wave per SIMD, pinned register files
     constexpr int KP = DKL <= 128 ? 128 : ((DKL + 127) / 128) * 128;     // LDS pitch of a K row, elements
     constexpr int KCH = KP / 8;                                          // 16-byte chunks per K row
     constexpr int K_TILE = KT * KP * 2, V_TILE = DVS * KT * 2;           // bytes
     constexpr int K_PIECES = K_TILE / 1024, V_PIECES = V_TILE / 1024;    // 1-KiB LDS-DMA pieces
     constexpr int KPW = (K_PIECES + 3) / 4, VPW = (V_PIECES + 3) / 4;    // pieces per wave
     constexpr int NQS = DKL / 16, NDT = DVS / 32;
+    constexpr int RING = PIN ? 6 : 4;                                     // fragment sets in flight from LDS
+    constexpr int NQ_A = PIN ? ((256 - NDT * 16) / 4 < NQS ? (256 - NDT * 16) / 4 : NQS) : 0;  // Q fragments in AGPRs
     static_assert(DKL % 16 == 0 && DVS % 32 == 0 && K_TILE % 1024 == 0 && V_TILE % 1024 == 0, "tile shapes");
-    constexpr int SINK = 2 * (K_TILE + V_TILE);  // 1 KiB per wave: where DMA pieces go when there is no next tile
+    constexpr int STAGE = K_TILE + V_TILE;
+    constexpr int LDS_BUDGET = 152 * 1024 / ((DKL <= 128 && DVS <= 160) ? 2 : 1);  // two workgroups per CU when narrow
+    constexpr int NST = LDS_BUDGET / STAGE >= 4 ? 4 : (LDS_BUDGET / STAGE >= 3 ? 3 : 2);
+    constexpr int NP = KPW + VPW;                // DMA pieces per wave and tile -- ALWAYS exactly this many
+    static_assert((NST - 2) * NP <= 63, "the counted wait must fit vmcnt");
+    constexpr int SINK = NST * STAGE;            // 1 KiB per wave: where pieces without a destination tile go
     __shared__ __attribute__((aligned(16))) char smem[SINK + 4096];
 
     const int tid = threadIdx.x;
@@ -101,78 +155,72 @@ __global__ __launch_bounds__(256, (DKL <= 128 && DVS <= 160) ? 2 : 1) void xattn
     int t_end = t_begin + p.tiles_per_split;
     t_end = t_end < ntiles ? t_end : ntiles;
 
-    // ---- per-lane source offsets of this wave's DMA pieces (elements, relative to the tile's first key).  A tile
-    // that reaches past Tk (the last one) recomputes its sources with the key / column clamped instead.
-    auto k_source = [&](int pc, int k0, bool clamp) -> int64_t {  // element offset from Kg
+    // ---- per-lane source offsets of this wave's DMA pieces (elements, relative to the tile's first key).  Nothing is
+    // clamped per tile: the caller pads V^T rows with zeros to a multiple of 32 keys and guarantees that the 31 K rows
+    // behind key Tk - 1 are readable memory (they are masked by assignment, whatever they hold).  A piece index beyond
+    // this wave's share (ragged piece counts) re-reads piece 0's source into the per-wave sink: EVERY wave issues
+    // exactly NP pieces per tile, so the waits below can be counted.
+    auto k_source = [&](int pc) -> uint32_t {
         const int ci = pc * 64 + lane;               // LDS chunk index inside the K tile
         const int row = ci / KCH, pos = ci % KCH;
         int c = (pos & ~15) | ((pos ^ row) & 15);    // the logical chunk stored at this position
         c = c * 8 < p.dkp ? c : (p.dkp >> 3) - 1;    // pad chunks: any finite data (their Q fragment is zero)
-        int key = k0 + ((row & ~12) | ((row & 4) << 1) | ((row & 8) >> 1));  // tile row -> key: bits 2, 3 swapped
-        if (clamp) key = key < p.Tk ? key : p.Tk - 1;
-        return (int64_t)key * p.ldk + c * 8;
+        const int key = (row & ~12) | ((row & 4) << 1) | ((row & 8) >> 1);  // tile row -> key: bits 2, 3 swapped
+        return (uint32_t)(key * (int)p.ldk + c * 8);
     };
-    auto v_source = [&](int pc, int k0, bool clamp) -> int64_t {  // element offset from Vg
+    auto v_source = [&](int pc) -> uint32_t {
         const int ci = pc * 64 + lane;               // LDS chunk index inside the V^T tile: 4 chunks per row
         int row = ci >> 2;
-        int kcol = k0 + (((ci & 3) ^ ((row >> 2) & 3)) << 3);
+        const int kcol = ((ci & 3) ^ ((row >> 2) & 3)) << 3;
         row = d0 + row < p.dvp ? row : p.dvp - 1 - d0;   // rows beyond dvp: finite data, never stored
-        if (clamp) kcol = kcol + 8 <= p.ldvt ? kcol : (int)p.ldvt - 8;
-        return (int64_t)row * p.ldvt + kcol;
+        return (uint32_t)(row * (int)p.ldvt + kcol);
     };
     uint32_t koff[KPW], voff[VPW];   // (element offsets < 2^31: launcher)
 #pragma unroll
-    for (int i = 0; i < KPW; ++i) koff[i] = (uint32_t)k_source(wave + 4 * i, 0, false);
+    for (int i = 0; i < KPW; ++i) koff[i] = k_source(wave + 4 * i < K_PIECES ? wave + 4 * i : wave);
 #pragma unroll
-    for (int i = 0; i < VPW; ++i) voff[i] = (uint32_t)v_source(wave + 4 * i, 0, false);
+    for (int i = 0; i < VPW; ++i) voff[i] = v_source(wave + 4 * i < V_PIECES ? wave + 4 * i : wave);
 
-    // Fast path (every tile but one that reaches past Tk): piece i of the next tile = uniform tile base + the lane's
-    // precomputed 32-bit offset, issued between the MFMAs of the current tile -- ALWAYS issued, without a branch:
-    // when there is no next tile to stage this way the pieces re-read the current tile into a per-wave sink.  Slow
-    // path (the tail tile): every source is recomputed with the key / column clamped, in a rolled loop -- kept out of
-    // the unrolled main body so that none of its lane-constant address arithmetic is hoisted into registers that live
-    // across the tile loop.
-    char *stage_kb = smem + SINK + wave * 1024, *stage_vb = stage_kb;
+    // Piece i of tile kt = uniform tile base + the lane's precomputed 32-bit offset.  The pieces of tile kt + NST - 1
+    // are issued between the MFMAs of tile kt -- always, without a branch: when that tile does not exist they re-read
+    // valid memory into the sink.  Ring of NST stages; tile kt + NST - 1 overwrites the stage of tile kt - 1, which
+    // every wave left before the barrier at the top of tile kt.
+    char *stage_kb = nullptr, *stage_vb = nullptr;
     int stage_step = 0;
     const T *stage_k = Kg, *stage_v = Vg;
-    auto stage_begin = [&](int kt, int buf) {
-        stage_kb = smem + buf * (K_TILE + V_TILE) + wave * 1024;
-        stage_vb = stage_kb + K_TILE;
-        stage_step = 4096;
-        stage_k = Kg + (int64_t)kt * KT * p.ldk;
-        stage_v = Vg + kt * KT;
-    };
-    auto stage_none = [&]() {
-        stage_kb = stage_vb = smem + SINK + wave * 1024;
-        stage_step = 0;
-    };
-    auto stage_piece = [&](int i) {  // 0..KPW-1: K pieces, KPW..KPW+VPW-1: V^T pieces
-        // (the offset is made opaque so that its zero-extension is not hoisted out of the tile loop as a 64-bit
-        //  register pair per piece: "uniform base + zext(32-bit VGPR)" at the use selects the SGPR-base form of the DMA)
-        if (i < KPW) {
-            if (wave + 4 * i < K_PIECES) {
-                uint32_t &o = koff[i];
-                asm volatile("" : "+v"(o));
-                xattn_dma16((const char *)stage_k + 2 * (uint64_t)o, stage_kb + i * stage_step);
-            }
+    auto stage_begin = [&](int kt, int slot, bool real) {
+        if (real) {
+            stage_kb = smem + slot * STAGE + wave * 1024;
+            stage_vb = stage_kb + K_TILE;
+            stage_step = 4096;
+            stage_k = Kg + (int64_t)kt * KT * p.ldk;
+            stage_v = Vg + kt * KT;
         } else {
-            if (wave + 4 * (i - KPW) < V_PIECES) {
-                uint32_t &o = voff[i - KPW];
-                asm volatile("" : "+v"(o));
-                xattn_dma16((const char *)stage_v + 2 * (uint64_t)o, stage_vb + (i - KPW) * stage_step);
-            }
+            stage_kb = stage_vb = smem + SINK + wave * 1024;
+            stage_step = 0;
+            stage_k = Kg;
+            stage_v = Vg;
         }
     };
-    auto stage_slow = [&](int kt, int buf) {
-        char *kb_ = smem + buf * (K_TILE + V_TILE);
-        char *vb_ = kb_ + K_TILE;
-        const int k0 = kt * KT;
-#pragma unroll 1
-        for (int pc = wave; pc < K_PIECES; pc += 4) xattn_dma16(Kg + k_source(pc, k0, true), kb_ + pc * 1024);
-#pragma unroll 1
-        for (int pc = wave; pc < V_PIECES; pc += 4) xattn_dma16(Vg + v_source(pc, k0, true), vb_ + pc * 1024);
+    auto stage_piece = [&](auto PI) {  // 0..KPW-1: K pieces, KPW..NP-1: V^T pieces (compile-time index)
+        constexpr int i = decltype(PI)::value;
+        // (the offset is made opaque so that its zero-extension is not hoisted out of the tile loop as a 64-bit
+        //  register pair per piece: "uniform base + zext(32-bit VGPR)" at the use selects the SGPR-base form of the DMA)
+        if constexpr (i < KPW) {
+            uint32_t &o = koff[i];
+            asm volatile("" : "+v"(o));
+            char *dst = (4 * i + 4 <= K_PIECES || wave + 4 * i < K_PIECES) ? stage_kb + i * stage_step
+                                                                          : smem + SINK + wave * 1024;
+            xattn_dma16((const char *)stage_k + 2 * (uint64_t)o, dst);
+        } else {
+            constexpr int j = i - KPW;
+            uint32_t &o = voff[j];
+            asm volatile("" : "+v"(o));
+            char *dst = (4 * j + 4 <= V_PIECES || wave + 4 * j < V_PIECES) ? stage_vb + j * stage_step
+                                                                          : smem + SINK + wave * 1024;
+            xattn_dma16((const char *)stage_v + 2 * (uint64_t)o, dst);
+        }
     };
-    auto is_tail = [&](int kt) { return kt * KT + KT > p.Tk || kt * KT + KT > p.ldvt; };
 
     f32x16 oacc[NDT];
 #pragma unroll
@@ -199,89 +247,90 @@ __global__ __launch_bounds__(256, (DKL <= 128 && DVS <= 160) ? 2 : 1) void xattn
         asm volatile("" : "+v"(vaddr[s2]));
     }
 
-    if (t_begin < t_end) stage_slow(t_begin, 0);
+    // ---- prologue: tiles t_begin .. t_begin + NST - 2 in flight
+#pragma unroll
+    for (int j = 0; j < NST - 1; ++j) {
+        stage_begin(t_begin + j, j, t_begin + j < t_end);
+        xa_for<0, NP>([&](auto PI) { stage_piece(PI); });
+    }
+    int slot = 0;  // ring stage of tile kt
     for (int kt = t_begin; kt < t_end; ++kt) {
-        const int it = kt - t_begin;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (kt + 1 < t_end && !is_tail(kt + 1)) {
-            stage_begin(kt + 1, (it + 1) & 1);
-        } else {
-            if (kt + 1 < t_end) stage_slow(kt + 1, (it + 1) & 1);
-            stage_none();
+        // all but the youngest (NST - 2) tiles' pieces have landed: tile kt is complete in this wave's share; after
+        // the barrier in every wave's, and the stage of tile kt - 1 is free
+        // (a raw s_barrier: __syncthreads() would drain vmcnt to zero and with it the tiles in flight.  No LDS read
+        //  of this wave is outstanding here -- the MFMAs of the previous tile consumed them all.)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * NP) : "memory");
+        __builtin_amdgcn_s_barrier();
+        {
+            const int nslot = slot == 0 ? NST - 1 : slot - 1;  // = (slot + NST - 1) % NST: the stage tile kt - 1 had
+            stage_begin(kt + NST - 1, nslot, kt + NST - 1 < t_end);
         }
-        const char *kb = smem + (it & 1) * (K_TILE + V_TILE);
+        const char *kb = smem + slot * STAGE;
         const char *vb = kb + K_TILE;
+        slot = slot + 1 == NST ? 0 : slot + 1;
 
-        // ---- S^T = K Q^T.  Fragments are read one GROUP of k-steps ahead into a second register set (the wave is
-        // alone on its SIMD: nobody else hides its LDS latency), and scheduling barriers keep the compiler from
-        // hoisting every read of the tile to the top (which spills).  The next tile's DMA pieces ride between the MFMAs.
+        // ---- S^T = K Q^T.  The wave is alone on its SIMD (wide heads), so nobody else hides its LDS latency: the K
+        // fragments travel through a RING of RK registers sets, the read of k-step s + RK issued right behind the
+        // MFMA of k-step s (RK - 1 MFMAs = 160..220 cycles of cover); a scheduling barrier per step keeps the
+        // compiler from hoisting every read of the tile to the top (which spills).  The next tile's DMA pieces ride
+        // between the MFMAs.
         f32x16 sacc;
+        if constexpr (!PIN) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) sacc[j] = 0.f;
-        constexpr int SG = 4, NSG = (NQS + SG - 1) / SG;
-        V8 kf[2][SG];
-        auto k_group = [&](int g, V8 *dst) {
-#pragma unroll
-            for (int t = 0; t < SG; ++t) {
-                const int s = g * SG + t;
-                if (s < NQS) dst[t] = *(const V8 *)(kb + kaddr[s & 7] + 256 * (s >> 3));
-            }
-        };
-        k_group(0, kf[0]);
-#pragma unroll
-        for (int g = 0; g < NSG; ++g) {
-            if (g + 1 < NSG) k_group(g + 1, kf[(g + 1) & 1]);
-#pragma unroll
-            for (int t = 0; t < SG; ++t) {
-                const int s = g * SG + t;
-                if (s < NQS) {
-                    sacc = Op<DT>::mfma32(kf[g & 1][t], qf[s], sacc);
-                    if (s < KPW + VPW) stage_piece(s);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
+            for (int j = 0; j < 16; ++j) sacc[j] = 0.f;
         }
+        constexpr int RK = NQS < RING ? NQS : RING;
+        V8 kf[RK];
+        auto k_read = [&](int sx) { return *(const V8 *)(kb + kaddr[sx & 7] + 256 * (sx >> 3)); };
 #pragma unroll
-        for (int i = NQS; i < KPW + VPW; ++i) stage_piece(i);
-        // first V^T fragments: in flight during the softmax arithmetic
-        constexpr int DG = 2, NDG = (NDT + DG - 1) / DG;
-        V8 vf[2][2 * DG];
-        auto v_group = [&](int g, V8 *dst) {
-#pragma unroll
-            for (int t = 0; t < DG; ++t) {
-                const int d = g * DG + t;
-                if (d < NDT) {
-#pragma unroll
-                    for (int s2 = 0; s2 < 2; ++s2) dst[2 * t + s2] = *(const V8 *)(vb + vaddr[s2] + 2048 * d);
-                }
-            }
-        };
-        v_group(0, vf[0]);
+        for (int i = 0; i < RK; ++i) kf[i] = k_read(i);
         __builtin_amdgcn_sched_barrier(0);
+        xa_for<0, NQS>([&](auto SI) {
+            constexpr int sx = decltype(SI)::value;
+            if constexpr (!PIN) sacc = Op<DT>::mfma32(kf[sx % RK], qf[sx], sacc);
+            else if constexpr (sx == 0) xa_mfma_v0<DT, (0 < NQ_A)>(sacc, kf[0], qf[0]);
+            else xa_mfma_v<DT, (sx < NQ_A)>(sacc, kf[sx % RK], qf[sx]);
+            if constexpr (sx + RK < NQS) kf[sx % RK] = k_read(sx + RK);
+            if constexpr (sx < KPW + VPW) stage_piece(std::integral_constant<int, sx>{});
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        xa_for<NQS, KPW + VPW>([&](auto PI) { stage_piece(PI); });
+        // first V^T fragments: in flight during the softmax arithmetic.  Fragment f = 2 d + s2 (d tile, k-step).
+        constexpr int NVF = 2 * NDT, RV = NVF < RING ? NVF : RING;
+        V8 vf[RV];
+        auto v_read = [&](int f) { return *(const V8 *)(vb + vaddr[f & 1] + 2048 * (f >> 1)); };
+#pragma unroll
+        for (int i = 0; i < RV; ++i) vf[i] = v_read(i);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (PIN) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // MFMA write of S^T -> VALU reads
 
-        // ---- key mask / tail: accumulator register i is key k0 + 16 (i >> 3) + 8 hh + (i & 7)
+        // ---- key mask / tail: accumulator register i is key k0 + 16 (i >> 3) + 8 hh + (i & 7); one 32-bit word per
+        // tile (a SCALAR load: uniform address), bit j = key k0 + j is attendable
         const int k0 = kt * KT;
-        if (p.kv_mask || k0 + KT > p.Tk) {
-            bool valid = false;
-            if (lane < KT) {
-                const int key = k0 + lane;
-                valid = key < p.Tk;
-                if (valid && p.kv_mask) valid = p.kv_mask[(int64_t)b * p.Tk + key] != 0;
-            }
-            const uint32_t bits = (uint32_t)__builtin_amdgcn_ballot_w64(valid) >> (8 * hh);
+        if (p.key_bits || k0 + KT > p.Tk) {
+            // (constant address space: a SCALAR load -- a vector load would be waited for with vmcnt(0), i.e. with
+            //  every tile in flight; the words were written by xattn_keybits_kernel before this launch)
+            typedef const __attribute__((address_space(4))) uint32_t *cbits_t;
+            uint32_t word = p.key_bits ? ((cbits_t)(uintptr_t)p.key_bits)[(int64_t)b * ntiles + kt]
+                                       : (p.Tk - k0 >= 32 ? 0xffffffffu : ((1u << (p.Tk - k0)) - 1u));
+            const uint32_t bits = word >> (8 * hh);
 #pragma unroll
             for (int i = 0; i < 16; ++i)
                 if (!((bits >> (16 * (i >> 3) + (i & 7))) & 1u)) sacc[i] = -INFINITY;
         }
-        // ---- online softmax in base 2: p = exp2(s * c - m * c); a tile without an attendable key leaves m at -inf
+        // ---- online softmax in base 2: p = exp2(s * c - m_ref * c).  The reference point m_ref follows the running
+        // maximum LAZILY: it moves (and the accumulators are rescaled -- ~400 instructions with the accumulator in
+        // AGPRs) only when the maximum has grown by more than 2^10 since it was set, so p <= 1024 (fine in 16 bits,
+        // same relative precision) and after the first tiles a rescale is rare.  A tile without an attendable key
+        // leaves m_ref at -inf; while it is -inf the accumulators are still zero and nothing needs rescaling.
         float mx = -INFINITY;
 #pragma unroll
         for (int i = 0; i < 16; ++i) mx = fmaxf(mx, sacc[i]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * p.scale_log2;
-        const float m_new = fmaxf(m_run, mx);
+        const bool unset = m_run == -INFINITY;
+        const float m_new = (unset || mx > m_run + 10.0f) ? fmaxf(m_run, mx) : m_run;
         const float m_use = m_new == -INFINITY ? 0.f : m_new;
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);  // first attendable tile: exp2(-inf) = 0
+        const float alpha = unset ? 1.0f : __builtin_amdgcn_exp2f(m_run - m_use);
         m_run = m_new;
         float psum = 0.f;
 #pragma unroll
@@ -292,10 +341,26 @@ __global__ __launch_bounds__(256, (DKL <= 128 && DVS <= 160) ? 2 : 1) void xattn
         }
         l_run = l_run * alpha + psum;
         if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
+            // (one d tile at a time: with the accumulator in AGPRs every element travels AGPR -> VGPR -> AGPR, and
+            //  an unfenced fully unrolled loop would want 176 temporaries at once)
 #pragma unroll
-            for (int d = 0; d < NDT; ++d)
+            for (int d = 0; d < NDT; ++d) {
 #pragma unroll
-                for (int j = 0; j < 16; ++j) oacc[d][j] *= alpha;
+                for (int j = 0; j < 16; ++j) {
+                    if constexpr (PIN) {
+                        // explicit AGPR -> VGPR -> AGPR round trip INSIDE the branch: written as plain arithmetic
+                        // the compiler hoists the copies of the whole accumulator out of it, into every tile
+                        float v;
+                        asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(oacc[d][j]));
+                        v *= alpha;
+                        asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(oacc[d][j]) : "v"(v));
+                    } else {
+                        oacc[d][j] *= alpha;
+                    }
+                }
+                if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (PIN) asm volatile("s_nop 7" ::: "memory");  // VALU write of O^T -> MFMA reads it as SrcC
         }
         // ---- P^T fragments: registers 8 s .. 8 s + 7 are keys 16 s + 8 hh + 0..7 = the B operand of k-step s
         V8 pf[2];
@@ -303,22 +368,19 @@ __global__ __launch_bounds__(256, (DKL <= 128 && DVS <= 160) ? 2 : 1) void xattn
         for (int s = 0; s < 2; ++s)
 #pragma unroll
             for (int j = 0; j < 8; ++j) pf[s][j] = Op<DT>::from_f32(sacc[8 * s + j]);
-        // ---- O^T += V^T P^T: the A fragment of (d tile, k-step s) is ONE 16-byte chunk of V^T row 32 d + r32
+        // ---- O^T += V^T P^T: the A fragment of (d tile, k-step s2) is ONE 16-byte chunk of V^T row 32 d + r32
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int g = 0; g < NDG; ++g) {
-            if (g + 1 < NDG) v_group(g + 1, vf[(g + 1) & 1]);
-#pragma unroll
-            for (int t = 0; t < DG; ++t) {
-                const int d = g * DG + t;
-                if (d < NDT) {
-#pragma unroll
-                    for (int s2 = 0; s2 < 2; ++s2) oacc[d] = Op<DT>::mfma32(vf[g & 1][2 * t + s2], pf[s2], oacc[d]);
-                }
-            }
+        if constexpr (PIN) asm volatile("s_nop 3" ::: "memory");  // VALU write of P^T -> MFMA reads it as SrcB
+        xa_for<0, NVF>([&](auto FI) {
+            constexpr int f = decltype(FI)::value;
+            constexpr int d = f >> 1, s2 = f & 1;
+            if constexpr (PIN) xa_mfma_a<DT>(oacc[d], vf[f % RV], pf[s2]);
+            else oacc[d] = Op<DT>::mfma32(vf[f % RV], pf[s2], oacc[d]);
+            if constexpr (f + RV < NVF) vf[f % RV] = v_read(f + RV);
             __builtin_amdgcn_sched_barrier(0);
-        }
+        });
     }
+    if constexpr (PIN) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // last MFMA write of O^T -> VALU reads
 
     // ---- epilogue
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
@@ -362,6 +424,21 @@ __global__ __launch_bounds__(256, (DKL <= 128 && DVS <= 160) ? 2 : 1) void xattn
                 *(V4 *)(orow + col) = o;
             }
         }
+}
+
+// One 32-bit word per (sample, key tile): bit j = key 32 t + j exists (< Tk) and its mask byte is non-zero.
+__global__ __launch_bounds__(256) void xattn_keybits_kernel(const uint8_t *kv_mask, uint32_t *bits, int Tk, int ntiles,
+                                                            int64_t total_words) {
+    const int64_t w = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);  // one 32-lane half-wave per word
+    const int j = threadIdx.x & 31;
+    bool valid = false;
+    if (w < total_words) {
+        const int64_t b = w / ntiles;
+        const int key = (int)(w % ntiles) * 32 + j;
+        valid = key < Tk && kv_mask[b * Tk + key] != 0;
+    }
+    const uint64_t bal = __builtin_amdgcn_ballot_w64(valid);
+    if (j == 0 && w < total_words) bits[w] = (threadIdx.x & 32) ? (uint32_t)(bal >> 32) : (uint32_t)bal;
 }
 
 // Combines the key splits of one (batch, head, query row): O = sum_s O_s 2^(m_s - M) / sum_s l_s 2^(m_s - M).
@@ -409,13 +486,13 @@ struct XCfg {
     int dkl, dvs;
 };
 // the kernel instantiations, narrowest first
-constexpr XCfg kCfgs[] = {{32, 96}, {32, 160}, {128, 128}, {352, 352}, {512, 256}, {704, 352}};
+constexpr XCfg kCfgs[] = {{32, 96}, {32, 160}, {128, 128}, {352, 192}, {512, 256}, {704, 352}};
 
 const XCfg *xattn_cfg(int dkp, int dvp) {
     for (const XCfg &c : kCfgs) {
         if (dkp > c.dkl) continue;
         // a head wider than one slice is cut into dv slices (each recomputes S): only where Q + O do not fit otherwise
-        const bool sliced = c.dkl >= 512;
+        const bool sliced = c.dkl >= 352;
         if (dvp <= c.dvs || (sliced && dvp <= c.dkl)) return &c;
     }
     return nullptr;
@@ -424,24 +501,27 @@ const XCfg *xattn_cfg(int dkp, int dvp) {
 
 bool xattn_supported(int dkp, int dvp) { return xattn_cfg(dkp, dvp) != nullptr; }
 
-// key splits for a launch: enough workgroups for ~2 per CU when batch x heads x query tiles x slices alone give
-// fewer than one per CU, each split keeping at least 8 key tiles
+// key splits for a launch: about one workgroup per CU and resident slot (wide heads hold one workgroup per CU, narrow
+// ones two) when batch x heads x query tiles x slices alone give clearly fewer, each split keeping >= 8 key tiles.
+// The partials cost HBM traffic (4 dv bytes per query row and split, written and read back): no more splits than that.
 int xattn_splits(int dkp, int dvp, int B, int H, int Tq, int Tk) {
     const XCfg *c = xattn_cfg(dkp, dvp);
     if (!c) return 1;
     const int nslice = (dvp + c->dvs - 1) / c->dvs;
     const int64_t base = (int64_t)B * H * ((Tq + 127) / 128) * nslice;
     const int ntiles = (Tk + 31) / 32;
-    if (base >= 200 || ntiles < 16) return 1;
-    int64_t s = (512 + base - 1) / base;
+    const int64_t target = (c->dkl <= 128 && c->dvs <= 160) ? 512 : 256;
+    if (base * 5 >= target * 4 || ntiles < 16) return 1;
+    int64_t s = (target + base - 1) / base;
     if (s > ntiles / 8) s = ntiles / 8;
     return s < 1 ? 1 : (int)s;
 }
 
+// scratch of one launch: the key-bit words of a masked launch [B][ntiles], then the fp32 partials of the key splits
+static size_t keybits_bytes(int B, int Tk) { return ((size_t)B * ((Tk + 31) / 32) * 4 + 255) & ~(size_t)255; }
 size_t xattn_partial_bytes(int dkp, int dvp, int B, int H, int Tq, int Tk) {
     const int s = xattn_splits(dkp, dvp, B, H, Tq, Tk);
-    if (s <= 1) return 0;
-    return (size_t)B * H * s * Tq * ((size_t)dvp * 4 + 8) + 512;
+    return keybits_bytes(B, Tk) + (s <= 1 ? 0 : (size_t)B * H * s * Tq * ((size_t)dvp * 4 + 8) + 512);
 }
 
 int xattn_launch(int dtype, int dkp, int dvp, int dk_logical, const void *Q, const void *K, const void *VT, void *O,
@@ -461,19 +541,26 @@ int xattn_launch(int dtype, int dkp, int dvp, int dk_logical, const void *Q, con
     const int nsplit = xattn_splits(dkp, dvp, B, H, Tq, Tk);
     const int ntiles = (Tk + 31) / 32;
     const int tps = (ntiles + nsplit - 1) / nsplit;
-    if (nsplit > 1 && !partials) return PIO_E_WORKSPACE;
+    if ((nsplit > 1 || kv_mask) && !partials) return PIO_E_WORKSPACE;
+    if (ldvt % 32) return PIO_E_ALIGN;  // V^T rows are read in whole 32-key tiles (zero padded by the caller)
     const int64_t nwg = (int64_t)B * H * nqt * nslice * nsplit;
     if (nwg > 0x7fffffffLL) return PIO_E_SHAPE;
     XattnParams p{};
     p.Q = Q; p.K = K; p.VT = VT; p.O = O;
-    p.part_o = (float *)partials;
-    p.part_ml = nsplit > 1 ? (float *)partials + (size_t)B * H * nsplit * Tq * dvp : nullptr;
-    p.kv_mask = kv_mask; p.q_mask = q_mask;
+    p.key_bits = kv_mask ? (const uint32_t *)partials : nullptr;
+    p.part_o = (float *)((char *)partials + keybits_bytes(B, Tk));
+    p.part_ml = nsplit > 1 ? p.part_o + (size_t)B * H * nsplit * Tq * dvp : nullptr;
+    p.q_mask = q_mask;
     p.Tq = Tq; p.Tk = Tk; p.H = H; p.nqt = nqt; p.nslice = nslice; p.nsplit = nsplit; p.tiles_per_split = tps;
     p.dkp = dkp; p.dvp = dvp;
     p.ldq = ldq; p.ldk = ldk; p.ldvt = ldvt; p.ldo = ldo; p.sQb = sQb; p.sKb = sKb; p.sVb = sVb; p.sOb = sOb;
     p.scale_log2 = 1.4426950408889634f / sqrtf((float)dk_logical);
     dim3 grid((unsigned)nwg, 1, 1), block(256, 1, 1);
+    if (kv_mask) {
+        const int64_t words = (int64_t)B * ntiles;
+        hipLaunchKernelGGL(xattn_keybits_kernel, dim3((unsigned)((words + 7) / 8)), block, 0, s, kv_mask,
+                           (uint32_t *)partials, Tk, ntiles, words);
+    }
     {
         // S recomputed per dv slice counts once: algorithmic flops of the reference formulation
         ProfScope prof(PROF_FLASH, 2.0 * B * H * (double)Tq * Tk * (dkp + dvp),
@@ -486,7 +573,7 @@ int xattn_launch(int dtype, int dkp, int dvp, int dk_logical, const void *Q, con
         if (c->dkl == 32 && c->dvs == 96) PIO_XA(32, 96);
         else if (c->dkl == 32) PIO_XA(32, 160);
         else if (c->dkl == 128) PIO_XA(128, 128);
-        else if (c->dkl == 352) PIO_XA(352, 352);
+        else if (c->dkl == 352) PIO_XA(352, 192);
         else if (c->dkl == 512) PIO_XA(512, 256);
         else PIO_XA(704, 352);
 #undef PIO_XA
