@@ -166,9 +166,10 @@ struct AttnScratch {
         const int64_t tkv = round_up(Tk, 32);  // V^T row pitch: whole 32-key tiles, zero padded (pio_xattn.hip)
         const bool sp = a.act_split != 0;
         q16 = take_pair(c, (size_t)Bq * Tq * ldq, sp);
-        // (+ 32 rows: the fused cross-attention kernel reads whole 32-key tiles; the rows behind key Tk - 1 only have
-        //  to be readable -- their scores are masked by assignment)
-        k16 = take_pair(c, (size_t)(B * (int64_t)Tk + 32) * ldq, sp);
+        // (the fused cross-attention kernel reads whole 32-key tiles: up to 31 rows behind key Tk - 1 of the last
+        //  sample.  They only have to be readable -- their scores are masked by assignment -- and they are: vt16 and
+        //  o16 follow in the same workspace.  No padding here: the fused q|k|v form needs q16 | k16 | vt16 adjacent.)
+        k16 = take_pair(c, (size_t)B * Tk * ldq, sp);
         vt16 = take_pair(c, (size_t)B * ldo * tkv, sp);
         scores = nullptr;
         p16 = Pair();
