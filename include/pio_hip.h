@@ -42,7 +42,9 @@ enum {
     PIO_E_ARCH = -3,      /* device is not gfx950                                   */
     PIO_E_WORKSPACE = -4, /* workspace too small                                    */
     PIO_E_LAUNCH = -5,    /* HIP launch error (hipGetLastError)                     */
-    PIO_E_ARG = -6        /* NULL / invalid argument                                */
+    PIO_E_ARG = -6,       /* NULL / invalid argument                                */
+    PIO_E_RANGE = -7      /* values left the range of the 16-bit operand dtype (raised by the host-side guard of the
+                             LayerNorm-folded stack, whose residual stream is an fp16 pair: see pio_ln_fold_t)     */
 };
 
 /* operand dtype of the MFMA matrices (accumulation is always fp32) */

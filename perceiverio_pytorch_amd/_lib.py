@@ -19,7 +19,7 @@ PIO_DT_BF16 = 1
 
 PIO_OK = 0
 _ERRORS = {-1: "PIO_E_SHAPE", -2: "PIO_E_ALIGN", -3: "PIO_E_ARCH", -4: "PIO_E_WORKSPACE", -5: "PIO_E_LAUNCH",
-           -6: "PIO_E_ARG"}
+           -6: "PIO_E_ARG", -7: "PIO_E_RANGE"}
 
 
 class PioError(RuntimeError):

@@ -122,6 +122,7 @@ const char *pio_error_string(int code) {
         case PIO_E_WORKSPACE: return "workspace too small";
         case PIO_E_LAUNCH: return "HIP launch failed";
         case PIO_E_ARG: return "invalid argument";
+        case PIO_E_RANGE: return "values outside the range of the 16-bit operand dtype";
         default: return "unknown error";
     }
 }

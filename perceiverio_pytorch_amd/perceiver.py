@@ -71,10 +71,27 @@ class PerceiverEncoder(nn.Module):
         nsplit = R.batch_streams()
         if nsplit <= 1 or B < 2 * nsplit or B % nsplit:
             ws = R.workspace(dev, lib.pio_encoder_workspace_bytes(cross, layers, Lyr, B, M, N))
-            with R.on_device(dev):
-                L.check(lib.pio_encoder_fwd(cross, layers, Lyr, self._num_blocks, R.tensor3(x), R.tensor3(z0), im_ptr,
-                                            out.data_ptr(), ws.data_ptr(), ws.numel(), R.stream_ptr(dev)),
-                        "pio_encoder_fwd")
+
+            def run():
+                with R.on_device(dev):
+                    L.check(lib.pio_encoder_fwd(cross, layers, Lyr, self._num_blocks, R.tensor3(x), R.tensor3(z0),
+                                                im_ptr, out.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                R.stream_ptr(dev)), "pio_encoder_fwd")
+            run()
+            # fp16 range guard of the LayerNorm-folded stack (runtime.range_check): the fold is offered for 1024-channel
+            # stacks with >= 2048 rows under the single-sweep policies (pio_ln_fold_t)
+            dtype, wlevel, split = R.policy_dtype()
+            if (R.range_check() and Lyr > 0 and wlevel == 0 and not split and D == 1024 and B * N >= 2048
+                    and not bool(torch.isfinite(out).all())):
+                prev = lib.pio_ln_fold_enable(0)
+                try:
+                    run()
+                finally:
+                    lib.pio_ln_fold_enable(prev)
+                if not bool(torch.isfinite(out).all()):
+                    raise L.PioError("PerceiverEncoder.forward: PIO_E_RANGE -- non-finite latents with and without the "
+                                     "LayerNorm fold: activations exceed the fp16 operand range (65504); use the "
+                                     "precision policy 'bf16x3' for this model")
             return R.forward_only(out, inputs, latents, *self.parameters())
         # Samples are independent: run `nsplit` batch slices as independent kernel chains on side streams so that
         # one chain's fill / drain / HBM-bound kernels overlap the other's MFMA-bound ones (each slice still fills

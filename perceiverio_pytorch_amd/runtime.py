@@ -72,6 +72,27 @@ def policy_dtype(name: Optional[str] = None) -> Tuple[int, bool, bool]:
     return _POLICIES[name or _policy]
 
 
+# ------------------------------------------------------------------------------------------------
+# range guard of the LayerNorm-folded stack.  Inside it the residual stream is an fp16 PAIR (hi + lo) and the GEMMs
+# read the un-normalised hi half: a latent beyond +-65504 becomes inf (the un-folded path keeps the stream in fp32 and
+# only ever rounds LayerNorm OUTPUTS, which are O(1)).  With the guard on (default; PIO_RANGE_CHECK=0 or
+# set_range_check(False) turns it off) PerceiverEncoder.forward checks the stack's output for non-finite values when
+# the fold was eligible, re-runs the call with the fold off if it finds any, and raises PIO_E_RANGE if that does not
+# help (then the model needs a wider operand type: precision policy "bf16x3").  Cost: one reduction over the latents
+# and a host sync per encoder call.
+# ------------------------------------------------------------------------------------------------
+_range_check = os.environ.get("PIO_RANGE_CHECK", "1") != "0"
+
+
+def range_check() -> bool:
+    return _range_check
+
+
+def set_range_check(on: bool) -> None:
+    global _range_check
+    _range_check = bool(on)
+
+
 def pad8(c: int) -> int:
     return (c + 7) & ~7
 

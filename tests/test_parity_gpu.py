@@ -932,3 +932,68 @@ def test_fused_cross_attention_vs_oracle(dev, case, policy):
     full = _t(mask3 if mask3 is not None else np.ones((B, Tq, Tk), bool), dev)
     ym = m(xq_t, _t(xkv, dev), _t(xkv, dev), attention_mask=full)
     _assert_close(y, ym.detach().cpu().numpy(), tol, what=f"fused vs materialised {case} {policy}")
+
+
+# ----------------------------------------------------------------------------------------------------
+# fp16 range: the LayerNorm-folded stack carries the residual stream as an fp16 pair
+# ----------------------------------------------------------------------------------------------------
+def _fold_stack(dev, scale, offset=0.0, outlier=0.0):
+    """A 1024-channel PerceiverEncoder (2 shared layers x 2 blocks) on 2048 latent rows whose latent table is scaled /
+    shifted: returns (folded fp16, un-folded fp16, fp16x3) outputs and whether the guard re-ran the call."""
+    from perceiverio_pytorch_amd import runtime as R
+    from perceiverio_pytorch_amd.perceiver import PerceiverEncoder
+    import perceiverio_pytorch_amd as P
+    lib = P.lib()
+    C_, N, D, Lyr = 64, 512, 1024, 2
+    p_enc = O.gen_encoder(C_, N, D, Lyr, seed=77)
+    lat = p_enc["latent_pos_enc.pos_embs"] * scale + offset
+    if outlier:
+        lat[:, 7] = outlier                      # one channel far from the others
+    p_enc["latent_pos_enc.pos_embs"] = lat.astype(np.float32)
+    enc = PerceiverEncoder(C_, Lyr, 2, N, D, num_self_attend_heads=8)
+    enc.load_state_dict(_sd(p_enc, "cpu"))
+    enc = enc.to(dev).eval()
+    x = _t(np.random.default_rng(3).standard_normal((4, 96, C_)).astype(np.float32), dev)
+    outs = {}
+    prev = lib.pio_ln_fold_enable(1)
+    try:
+        _policy("fp16")
+        outs["fold"] = enc(x, enc.latents(x)).clone()
+        lib.pio_ln_fold_enable(0)
+        outs["plain"] = enc(x, enc.latents(x)).clone()
+        _policy("fp16x3")
+        outs["x3"] = enc(x, enc.latents(x)).clone()
+    finally:
+        lib.pio_ln_fold_enable(prev)
+        _policy("fp16x3")
+    return outs
+
+
+def test_fold_range_guard_falls_back_on_overflow(dev):
+    """Latents beyond the fp16 range (65504): the folded stack alone would return inf / nan; with the guard
+    (runtime.range_check, default on) the call is re-run un-folded and matches the un-folded result bit for bit."""
+    from perceiverio_pytorch_amd import runtime as R
+    assert R.range_check()
+    outs = _fold_stack(dev, scale=3.0e5)                       # |latents| up to ~1e6 >> 65504
+    assert torch.isfinite(outs["fold"]).all(), "the guard must have replaced the overflowed result"
+    assert torch.equal(outs["fold"], outs["plain"])
+    _assert_close(outs["plain"], outs["x3"].cpu().numpy(), TOL, what="un-folded fp16 vs fp16x3 at |x| ~ 1e6")
+    R.set_range_check(False)
+    try:
+        raw = _fold_stack(dev, scale=3.0e5)["fold"]
+    finally:
+        R.set_range_check(True)
+    assert not torch.isfinite(raw).all(), "without the guard the fp16-pair stream overflows (documented behaviour)"
+
+
+@pytest.mark.parametrize("kind", ["dc_offset_30sigma", "outlier_channel_1e4"])
+def test_fold_on_adversarial_rows(dev, kind):
+    """Rows with a DC offset of 30 sigma, or one channel near 1e4: the fold computes var = E[x^2] - mean^2 in fp32 from
+    per-128-column partial sums and reads the un-normalised fp16 stream -- held to the same 1e-3 as the un-folded path
+    against the float32-grade policy."""
+    outs = _fold_stack(dev, scale=1.0, offset=15.0) if kind == "dc_offset_30sigma" else \
+        _fold_stack(dev, scale=1.0, outlier=1.0e4)
+    ref = outs["x3"].cpu().numpy()
+    e_fold, e_plain = _errs(outs["fold"], ref), _errs(outs["plain"], ref)
+    print(f"{kind}: fold relL2={e_fold[0]:.2e} max={e_fold[1]:.2e} | un-folded relL2={e_plain[0]:.2e} max={e_plain[1]:.2e}")
+    assert e_fold[0] <= TOL and e_fold[1] <= TOL, (kind, e_fold, e_plain)

@@ -58,9 +58,28 @@ for k, (tot, n) in fam.items():
         traffic[k] = {"bytes_per_launch": tot / max(n, 1), "launches": n, "family_of": sorted(
             x for x in traffic if x.startswith(k + "<"))}
 res["traffic"] = traffic
+# Matrix-pipe occupancy per kernel from the counters: SQ_VALU_MFMA_BUSY_CYCLES (summed over every SIMD of the chip:
+# 16 cycles per v_mfma_f32_16x16x32, 32 per 32x32x16) / (GRBM_GUI_ACTIVE / 8 XCDs = active cycles of the launch at the
+# clock the chip held) / (256 CUs x 4 SIMDs).  This is occupancy AT THE HELD CLOCK; the fraction of the 2.5 PFLOP/s
+# datasheet peak is lower by held clock / 2.4 GHz (MI355X_MICROARCH.md, DVFS give-back).
+f = newest(f"{out}/pmc_mfma/*/*counter_collection.csv")
+mf = collections.defaultdict(lambda: [0.0, 0.0, 0])
+if f:
+    for r in csv.DictReader(open(f[0])):
+        a = mf[short(r["Kernel_Name"])]
+        if r["Counter_Name"] == "SQ_VALU_MFMA_BUSY_CYCLES":
+            a[0] += float(r["Counter_Value"])
+            a[2] += 1
+        elif r["Counter_Name"] == "GRBM_GUI_ACTIVE":
+            a[1] += float(r["Counter_Value"])
+res["mfma_busy"] = {k: {"launches": v[2], "mfma_busy_cycles_per_launch": v[0] / max(v[2], 1),
+                        "gui_active_cycles_per_launch_per_xcd": v[1] / 8.0 / max(v[2], 1),
+                        "mfma_pipe_occupancy": v[0] / max(v[1] / 8.0 * 1024.0, 1.0)}
+                    for k, v in mf.items() if k.startswith("pio::") and v[2]}
 try:
     res["bench"] = json.loads(open(f"{out}/bench.json").read().strip().splitlines()[-1])
 except Exception as e:  # noqa: BLE001
     res["bench"] = {"error": str(e)}
 json.dump(res, open(f"{out}/summary_{tag}.json", "w"), indent=1)
-print(json.dumps({"kernel_stats": res["kernel_stats"][:6], "traffic": traffic}, indent=1)[:3000])
+print(json.dumps({"kernel_stats": res["kernel_stats"][:6], "traffic": traffic, "mfma_busy": res["mfma_busy"]},
+                 indent=1)[:5000])
