@@ -198,6 +198,13 @@ int pio_pack_linear(const float *w, const float *bias, int32_t out, int32_t in, 
 int pio_layernorm_cast(const pio_tensor3_t *x, const pio_layernorm_t *ln, void *y, void *y_lo, int32_t c_pad,
                        int32_t dtype, void *stream);
 
+/* The same LayerNorm over the channel-wise CONCATENATION [x1 | x2] of two arrays, never materialised: x1 [B,T,C1],
+ * x2 [B,T,C2] or ONE batch-invariant table [1,T,C2] (x2->B == 1); ln->c == C1 + C2; C1, C2 even, rows 8-byte aligned.
+ * Replaces torch.cat([features, position_features], -1) of preprocessors.py:176-200 followed by layer_norm_kv
+ * (transformer_primitives.py:379); bit-identical to pio_layernorm_cast of the concatenated array. */
+int pio_layernorm_cast_cat(const pio_tensor3_t *x1, const pio_tensor3_t *x2, const pio_layernorm_t *ln, void *y,
+                           void *y_lo, int32_t c_pad, int32_t dtype, void *stream);
+
 /* C = epilogue(alpha * A B^T): A [M,K], B [N,K] operand dtype, K contiguous (multiple of 8).
  * Batched over z = zb*nh + zh with element strides; bias_mode 0 none / 1 per column / 2 per row;
  * act 0 none / 1 exact-erf GELU (F.gelu, transformer_primitives.py:214); optional fp32 residual R
@@ -291,6 +298,15 @@ int pio_encoder_fwd(const pio_cross_attention_t *cross, const pio_self_attention
                     int32_t num_blocks, const pio_tensor3_t *inputs, const pio_tensor3_t *latents,
                     const uint8_t *input_mask, float *out, void *workspace, size_t workspace_bytes,
                     void *stream);
+
+/* The same with the encoder input given as two channel-wise concatenated arrays [inputs | inputs_tail] (inputs_tail
+ * may be NULL = pio_encoder_fwd; inputs_tail->B == 1: one batch-invariant table): the ImageNet preprocessor's 64 conv
+ * features [B,3136,64] and its [3136,258] Fourier table instead of the replicated [B,3136,322] array
+ * (preprocessors.py:176-200).  Workspace as pio_encoder_workspace_bytes. */
+int pio_encoder_fwd_split(const pio_cross_attention_t *cross, const pio_self_attention_t *layers, int32_t L,
+                          int32_t num_blocks, const pio_tensor3_t *inputs, const pio_tensor3_t *inputs_tail,
+                          const pio_tensor3_t *latents, const uint8_t *input_mask, float *out, void *workspace,
+                          size_t workspace_bytes, void *stream);
 
 /* PerceiverDecoder.forward (perceiver.py:166-180): cross-attend(query <- latents, query mask) and the
  * optional final nn.Linear (final == NULL => final_project=False).  out [B,Q,out_channels] fp32. */

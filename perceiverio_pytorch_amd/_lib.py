@@ -100,6 +100,7 @@ SIGNATURES = {
     "pio_packed_weight_bytes": (_sz, [_i32, _i32, _i32, _i32]),
     "pio_pack_linear": (C.c_int, [_vp, _vp, _i32, _i32, _i64, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "pio_layernorm_cast": (C.c_int, [P(Tensor3), P(LayerNorm), _vp, _vp, _i32, _i32, _vp]),
+    "pio_layernorm_cast_cat": (C.c_int, [P(Tensor3), P(Tensor3), P(LayerNorm), _vp, _vp, _i32, _i32, _vp]),
     "pio_gemm_nt": (C.c_int, [P(Gemm), _vp]),
     "pio_softmax_rows": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _f, _vp, _vp, _vp, _vp, _i32, _vp]),
     "pio_attention_workspace_bytes": (_sz, [P(Attention), _i32, _i32, _i32]),
@@ -115,6 +116,8 @@ SIGNATURES = {
     "pio_encoder_workspace_bytes": (_sz, [P(CrossAttention), P(SelfAttention), _i32, _i32, _i32, _i32]),
     "pio_encoder_fwd": (C.c_int, [P(CrossAttention), P(SelfAttention), _i32, _i32, P(Tensor3), P(Tensor3), _vp, _vp,
                                   _vp, _sz, _vp]),
+    "pio_encoder_fwd_split": (C.c_int, [P(CrossAttention), P(SelfAttention), _i32, _i32, P(Tensor3), P(Tensor3),
+                                        P(Tensor3), _vp, _vp, _vp, _sz, _vp]),
     "pio_decoder_workspace_bytes": (_sz, [P(CrossAttention), P(Linear), _i32, _i32, _i32]),
     "pio_decoder_fwd": (C.c_int, [P(CrossAttention), P(Linear), _i32, P(Tensor3), P(Tensor3), _vp, _vp, _vp, _sz,
                                   _vp]),

@@ -559,16 +559,23 @@ struct CrossPlan {
     }
 };
 
+// ikv_tail (optional): the key / value input arrives as TWO arrays whose channels are concatenated, [ikv | ikv_tail]
+// (ikv_tail->B == 1: one batch-invariant table, e.g. Fourier position features); layer_norm_kv runs over the virtual
+// concatenation and nothing is ever concatenated in HBM.
 static int cross_attention_run(const pio_cross_attention_t &ca, const pio_tensor3_t &iq, const pio_tensor3_t &ikv,
                                const uint8_t *kv_mask, const uint8_t *q_mask, const uint8_t *full_mask,
                                const float *attention_bias, float *out, float *probs_out, CrossPlan &p,
-                               hipStream_t s) {
+                               hipStream_t s, const pio_tensor3_t *ikv_tail = nullptr) {
     const int B = iq.B, Tq = iq.T, Tk = ikv.T;
     const int64_t rows = (int64_t)B * Tq;
-    if (iq.C != ca.attn.q_in || ikv.C != ca.attn.k_in || ikv.C != ca.attn.v_in || ikv.B != B) return PIO_E_SHAPE;
+    const int kv_c = ikv.C + (ikv_tail ? ikv_tail->C : 0);
+    if (iq.C != ca.attn.q_in || kv_c != ca.attn.k_in || kv_c != ca.attn.v_in || ikv.B != B) return PIO_E_SHAPE;
     if (ca.attn.out != iq.C || ca.mlp.in != iq.C || ca.mlp.out != iq.C) return PIO_E_SHAPE;
     // layer_norm_kv, layer_norm_q  (transformer_primitives.py:379-380)
-    PIO_TRY(cast_pair(ikv, &ca.ln_kv, p.kv16, pad8(ikv.C), ca.attn.dtype, s));
+    if (ikv_tail)
+        PIO_TRY(layernorm_cast_cat_launch(ikv, *ikv_tail, ca.ln_kv, p.kv16.hi, p.kv16.lo, pad8(kv_c), ca.attn.dtype, s));
+    else
+        PIO_TRY(cast_pair(ikv, &ca.ln_kv, p.kv16, pad8(ikv.C), ca.attn.dtype, s));
     const pio_tensor3_t q1 = p.q_bcast ? first_batch(iq) : iq;
     const Pair qa = pair_if(p.q16, ca.attn.act_split);
     PIO_TRY(cast_pair(q1, &ca.ln_q, qa, pad8(iq.C), ca.attn.dtype, s));
@@ -718,6 +725,14 @@ size_t pio_encoder_workspace_bytes(const pio_cross_attention_t *cross, const pio
 int pio_encoder_fwd(const pio_cross_attention_t *cross, const pio_self_attention_t *layers, int32_t L,
                     int32_t num_blocks, const pio_tensor3_t *inputs, const pio_tensor3_t *latents,
                     const uint8_t *input_mask, float *out, void *workspace, size_t workspace_bytes, void *stream) {
+    return pio_encoder_fwd_split(cross, layers, L, num_blocks, inputs, nullptr, latents, input_mask, out, workspace,
+                                 workspace_bytes, stream);
+}
+
+int pio_encoder_fwd_split(const pio_cross_attention_t *cross, const pio_self_attention_t *layers, int32_t L,
+                          int32_t num_blocks, const pio_tensor3_t *inputs, const pio_tensor3_t *inputs_tail,
+                          const pio_tensor3_t *latents, const uint8_t *input_mask, float *out, void *workspace,
+                          size_t workspace_bytes, void *stream) {
     if (!cross || !inputs || !latents || !out || !workspace || (L > 0 && !layers)) return PIO_E_ARG;
     if (L < 0 || num_blocks < 0) return PIO_E_SHAPE;
     hipStream_t s = (hipStream_t)stream;
@@ -730,7 +745,7 @@ int pio_encoder_fwd(const pio_cross_attention_t *cross, const pio_self_attention
         cp.carve(workspace, *cross, B, N, M, qb, true);
         // perceiver.py:99-103: only the cross-attend is masked, with mask[b,i,j] = input_mask[b,j]
         PIO_TRY(cross_attention_run(*cross, *latents, *inputs, input_mask, nullptr, nullptr, nullptr, out, nullptr,
-                                    cp, s));
+                                    cp, s, inputs_tail));
     }
     const pio_tensor3_t z = {out, (int64_t)N * D, D, B, N, D};
     FoldCarry carry;  // LayerNorm fold: the row statistics of z travel from one block's fc2 to the next block's q|k|v

@@ -149,6 +149,12 @@ int pio_layernorm_cast(const pio_tensor3_t *x, const pio_layernorm_t *ln, void *
     return layernorm_cast_launch(*x, ln, y, y_lo, c_pad, dtype, (hipStream_t)stream);
 }
 
+int pio_layernorm_cast_cat(const pio_tensor3_t *x1, const pio_tensor3_t *x2, const pio_layernorm_t *ln, void *y,
+                           void *y_lo, int32_t c_pad, int32_t dtype, void *stream) {
+    if (!x1 || !x2 || !ln) return PIO_E_ARG;
+    return layernorm_cast_cat_launch(*x1, *x2, *ln, y, y_lo, c_pad, dtype, (hipStream_t)stream);
+}
+
 int pio_gemm_nt(const pio_gemm_t *g, void *stream) {
     if (!g) return PIO_E_ARG;
     return gemm_nt_launch(*g, (hipStream_t)stream);

@@ -349,6 +349,104 @@ __global__ __launch_bounds__(256) void layernorm_cast_reg2_kernel(const float *_
     }
 }
 
+// LayerNorm over the CONCATENATION [x1 row | x2 row] without materialising it: x1 [B, T, C1] (e.g. the 64 conv features
+// of the ImageNet preprocessor), x2 [T, C2] or [B, T, C2] (the 258 Fourier position channels: ONE batch-invariant table,
+// stride_b == 0).  Same lane <-> channel mapping and arithmetic as layernorm_cast_reg2_kernel on the concatenated row,
+// so the result is bit-identical to LayerNorm(torch.cat([x1, x2], -1)) through that kernel; C1 and C2 even, rows 8-byte
+// aligned.  Replaces preprocessors.py:176-200's concat + transformer_primitives.py:379's layer_norm_kv: the encoder's
+// largest read drops from B x 3136 x 322 fp32 (129 MB at B = 32, 80 % of it the replicated table) to the 26 MB of
+// features plus one 3.2 MB table that stays in cache.
+template <int DT>
+__global__ __launch_bounds__(256) void layernorm_cast_cat2_kernel(const float *__restrict__ x1, int64_t sb1, int64_t st1,
+                                                                  int C1, const float *__restrict__ x2, int64_t sb2,
+                                                                  int64_t st2, int C2, int T, int64_t rows,
+                                                                  const float *__restrict__ gamma,
+                                                                  const float *__restrict__ beta, float eps,
+                                                                  typename Op<DT>::T *__restrict__ y,
+                                                                  typename Op<DT>::T *__restrict__ y_lo, int c_pad) {
+    typedef typename Op<DT>::T OT;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef OT OT2 __attribute__((ext_vector_type(2)));
+    constexpr int NV = 16;
+    const int C = C1 + C2;
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int64_t b = row / T, t = row % T;
+    const float *r1 = x1 + b * sb1 + t * st1;
+    const float *r2 = x2 + b * sb2 + t * st2 - C1;   // indexed with the concatenated channel
+    OT *yr = y + row * (int64_t)c_pad;
+    OT *ylr = y_lo ? y_lo + row * (int64_t)c_pad : nullptr;
+    f32x2 v[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int i = (j * 64 + lane) * 2;
+        v[j] = (i < C1) ? *(const f32x2 *)(r1 + i) : ((i < C) ? *(const f32x2 *)(r2 + i) : (f32x2){0.f, 0.f});
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) s += v[j][0] + v[j][1];
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int i = (j * 64 + lane) * 2;
+        if (i < C) {
+            const float d0 = v[j][0] - mean, d1 = v[j][1] - mean;
+            q += d0 * d0 + d1 * d1;
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int i = (j * 64 + lane) * 2;
+        if (i < c_pad) {
+            f32x2 f = {0.f, 0.f};
+            if (i < C) {
+                const f32x2 g = *(const f32x2 *)(gamma + i);
+                const f32x2 bb = *(const f32x2 *)(beta + i);
+                f[0] = (v[j][0] - mean) * rstd * g[0] + bb[0];
+                f[1] = (v[j][1] - mean) * rstd * g[1] + bb[1];
+            }
+            OT2 o, l;
+            o[0] = Op<DT>::from_f32(f[0]);
+            o[1] = Op<DT>::from_f32(f[1]);
+            l[0] = Op<DT>::from_f32(f[0] - Op<DT>::to_f32(o[0]));
+            l[1] = Op<DT>::from_f32(f[1] - Op<DT>::to_f32(o[1]));
+            *(OT2 *)(yr + i) = o;
+            if (ylr) *(OT2 *)(ylr + i) = l;
+        }
+    }
+}
+
+int layernorm_cast_cat_launch(const pio_tensor3_t &x1, const pio_tensor3_t &x2, const pio_layernorm_t &ln, void *y,
+                              void *y_lo, int c_pad, int dtype, hipStream_t s) {
+    if (!x1.data || !x2.data || !y || !ln.gamma || !ln.beta) return PIO_E_ARG;
+    const int C = x1.C + x2.C;
+    if (x1.B <= 0 || x1.T <= 0 || x1.C <= 0 || x2.C <= 0 || x2.T != x1.T || (x2.B != x1.B && x2.B != 1) || ln.c != C ||
+        c_pad < C || (c_pad % 8) || c_pad > 2048 || (x1.C & 1) || (x2.C & 1))
+        return PIO_E_SHAPE;
+    if (((uintptr_t)x1.data & 7) || ((uintptr_t)x2.data & 7) || (x1.stride_b & 1) || (x1.stride_t & 1) ||
+        (x2.stride_b & 1) || (x2.stride_t & 1) || ((uintptr_t)y & 3) || ((uintptr_t)y_lo & 3) ||
+        ((uintptr_t)ln.gamma & 7) || ((uintptr_t)ln.beta & 7))
+        return PIO_E_ALIGN;
+    const int64_t rows = (int64_t)x1.B * x1.T;
+    const int64_t sb2 = x2.B == 1 ? 0 : x2.stride_b;
+    const unsigned blocks = (unsigned)((rows + 3) / 4);
+    ProfScope prof(PROF_LAYERNORM, 0.0, (double)rows * (4.0 * x1.C + (y_lo ? 4.0 : 2.0) * c_pad) + 4.0 * x2.T * x2.C, s);
+    if (dtype == PIO_DT_F16)
+        hipLaunchKernelGGL((layernorm_cast_cat2_kernel<PIO_DT_F16>), dim3(blocks), dim3(256), 0, s, x1.data, x1.stride_b,
+                           x1.stride_t, x1.C, x2.data, sb2, x2.stride_t, x2.C, x1.T, rows, ln.gamma, ln.beta, ln.eps,
+                           (Op<PIO_DT_F16>::T *)y, (Op<PIO_DT_F16>::T *)y_lo, c_pad);
+    else if (dtype == PIO_DT_BF16)
+        hipLaunchKernelGGL((layernorm_cast_cat2_kernel<PIO_DT_BF16>), dim3(blocks), dim3(256), 0, s, x1.data, x1.stride_b,
+                           x1.stride_t, x1.C, x2.data, sb2, x2.stride_t, x2.C, x1.T, rows, ln.gamma, ln.beta, ln.eps,
+                           (Op<PIO_DT_BF16>::T *)y, (Op<PIO_DT_BF16>::T *)y_lo, c_pad);
+    else
+        return PIO_E_ARG;
+    return launch_status();
+}
+
 int layernorm_cast_launch(const pio_tensor3_t &x, const pio_layernorm_t *ln, void *y, void *y_lo, int c_pad,
                           int dtype, hipStream_t s) {
     if (!x.data || !y) return PIO_E_ARG;

@@ -94,6 +94,9 @@ int gemm_nt_launch(const pio_gemm_t &g, hipStream_t s);
 int gemm_kernel_override(int which);  // 0 auto, 128, 256, 1 = streaming; returns the previous choice
 int layernorm_cast_launch(const pio_tensor3_t &x, const pio_layernorm_t *ln, void *y, void *y_lo, int c_pad,
                           int dtype, hipStream_t s);
+// LayerNorm over the concatenation [x1 | x2] of two sources (x2 may be one batch-invariant table, B == 1)
+int layernorm_cast_cat_launch(const pio_tensor3_t &x1, const pio_tensor3_t &x2, const pio_layernorm_t &ln, void *y,
+                              void *y_lo, int c_pad, int dtype, hipStream_t s);
 // LayerNorm fold: 16-bit cast of contiguous 1024-channel rows + their per-128-column (sum, sum of squares), the form
 // the fold's consumer GEMM reads (first layer of a stack: later layers get both from the producing GEMM)
 int rowstats_cast_launch(const float *x, int64_t rows, void *y16, void *y16_lo, float *part, int dtype,

@@ -168,6 +168,19 @@ class _PosMixin:
         with_pos = torch.cat([feats, enc], dim=-1) if self._concat_or_add_pos == "concat" else feats + enc
         return with_pos, feats
 
+    def _split_pos(self, feats: torch.Tensor):
+        """(features [B,M,C1], position table [M,C2]) when the network input is their concatenation and the position
+        features are ONE batch-invariant table -- the form pio_encoder_fwd_split consumes without ever building the
+        replicated [B,M,C1+C2] array; None otherwise."""
+        if self._concat_or_add_pos != "concat" or self._n_extra_pos_mlp > 0:
+            return None
+        enc = self._positional_encoding(batch_size=feats.shape[0], pos=None, device=feats.device).to(feats.device)
+        if enc.dim() != 3 or (enc.shape[0] > 1 and enc.stride(0) != 0) or enc.shape[1] != feats.shape[1]:
+            return None
+        if (feats.shape[2] | enc.shape[2]) & 1:
+            return None
+        return feats, enc[0]
+
 
 class EmbeddingPreprocessor(nn.Module):
     """Token embedding + learned position embedding (preprocessors.py:18-54)."""
@@ -241,8 +254,7 @@ class ImagePreprocessor(nn.Module, _PosMixin):
     def n_output_channels(self):
         return self.output_channels
 
-    def forward(self, inputs: torch.Tensor, *, pos=None):
-        """inputs: [..., channel, height, width] (PyTorch image layout)."""
+    def _features(self, inputs: torch.Tensor) -> torch.Tensor:
         x = inputs
         if self._prep_type in ("conv", "conv1x1"):
             video = x.dim() == 5
@@ -271,7 +283,16 @@ class ImagePreprocessor(nn.Module, _PosMixin):
                 raise ValueError("Unsupported data format for pixels.")
         if x.dim() > 3:
             x = x.reshape(x.shape[0], int(math.prod(self.index_dims)), -1)
-        return self._attach_pos(x, pos)
+        return x
+
+    def forward(self, inputs: torch.Tensor, *, pos=None):
+        """inputs: [..., channel, height, width] (PyTorch image layout)."""
+        return self._attach_pos(self._features(inputs), pos)
+
+    def forward_split(self, inputs: torch.Tensor):
+        """The same network input as two arrays, (features [B,M,C1], position table [M,C2]), or None when this
+        configuration does not concatenate a batch-invariant position table (see _PosMixin._split_pos)."""
+        return self._split_pos(self._features(inputs))
 
 
 class OneHotPreprocessor(nn.Module):
@@ -324,9 +345,15 @@ class EmbeddingPostprocessor(nn.Module):
         self._embedding = embedding
         self._vocab_size, self._d_model = embedding.weight.shape
         self.bias = nn.Parameter(torch.zeros(self._vocab_size))
+        self._pio_linear = {}       # packed image of the tied weight (runtime.hip_linear)
 
     def forward(self, inputs: torch.Tensor, *, pos=None, modality_sizes=None) -> torch.Tensor:
         b, t, _ = inputs.shape
+        if inputs.is_cuda:
+            # the step right behind the decoder: [B*T, d_model] x [vocab, d_model]^T through libpio_hip.so
+            # (pio_gemm_nt) under the model's precision policy, not a torch matmul
+            from .runtime import hip_linear
+            return hip_linear(inputs, self._embedding.weight, self.bias, self._pio_linear)
         return (inputs.reshape(-1, self._d_model) @ self._embedding.weight.T + self.bias).reshape(b, t,
                                                                                                  self._vocab_size)
 

@@ -41,7 +41,7 @@ class ClassificationPerceiver(nn.Module):
     def __init__(self, num_classes: int = 1000, img_size: Sequence[int] = (224, 224), img_channels: int = 3,
                  prep_type: PrepType = PrepType.FOURIER_POS_CONVNET, num_self_attends_per_block: int = 6,
                  num_blocks: int = 8, num_latents: int = 512, num_latent_channels: int = 1024,
-                 precision_policy: str = DEFAULT_POLICY["ClassificationPerceiver"]):
+                 precision_policy: str = DEFAULT_POLICY["ClassificationPerceiver"], decode_row0_only: bool = False):
         super().__init__()
         self.precision_policy = precision_policy
         fourier = dict(concat_pos=True, num_bands=64, sine_only=False)
@@ -70,6 +70,16 @@ class ClassificationPerceiver(nn.Module):
             final_project_out_channels=num_classes,
             output_postprocessors=ClassificationPostprocessor(num_classes=num_classes, num_input_channels=num_classes,
                                                               project=False))
+        # opt-in: the postprocessor keeps query row 0 only (postprocessors.py:187), and decoder rows are independent
+        self.decode_row0_only = decode_row0_only
+
+    @property
+    def decode_row0_only(self) -> bool:
+        return self.perceiver.decoder_query_rows is not None
+
+    @decode_row0_only.setter
+    def decode_row0_only(self, on: bool) -> None:
+        self.perceiver.decoder_query_rows = slice(0, 1) if on else None
 
     def forward(self, img: torch.Tensor):
         """img: (batch, channels, H, W) -> logits (batch, num_classes)."""

@@ -53,6 +53,13 @@ class PerceiverEncoder(nn.Module):
         return self.latent_pos_enc(batch_size=inputs.shape[0])
 
     def forward(self, inputs, latents, *, input_mask=None):
+        """Reference signature (perceiver.py:98).  Extension: `inputs` may be a pair (features [B,M,C1], table [M,C2] or
+        [1,M,C2]) standing for their channel-wise concatenation with the table broadcast over the batch -- the
+        encoder then never sees a materialised [B,M,C1+C2] array (pio_encoder_fwd_split)."""
+        inputs_tail = None
+        if isinstance(inputs, (tuple, list)):
+            inputs, inputs_tail = inputs
+            inputs_tail = R.as_f32_3d(inputs_tail if inputs_tail.dim() == 3 else inputs_tail[None])
         R.require_device(inputs, "PerceiverEncoder.forward")
         if self.training and any(m.dropout.p > 0 for m in self.self_attends):
             raise NotImplementedError("the HIP path is forward/inference only")
@@ -68,15 +75,16 @@ class PerceiverEncoder(nn.Module):
             layers[i] = sa._desc()
         im, im_ptr = R.mask_u8(input_mask, (B, M), dev)
         out = torch.empty((B, N, D), dtype=torch.float32, device=dev)
+        tail3 = R.tensor3(inputs_tail) if inputs_tail is not None else None
         nsplit = R.batch_streams()
-        if nsplit <= 1 or B < 2 * nsplit or B % nsplit:
+        if nsplit <= 1 or B < 2 * nsplit or B % nsplit or inputs_tail is not None:
             ws = R.workspace(dev, lib.pio_encoder_workspace_bytes(cross, layers, Lyr, B, M, N))
 
             def run():
                 with R.on_device(dev):
-                    L.check(lib.pio_encoder_fwd(cross, layers, Lyr, self._num_blocks, R.tensor3(x), R.tensor3(z0),
-                                                im_ptr, out.data_ptr(), ws.data_ptr(), ws.numel(),
-                                                R.stream_ptr(dev)), "pio_encoder_fwd")
+                    L.check(lib.pio_encoder_fwd_split(cross, layers, Lyr, self._num_blocks, R.tensor3(x), tail3,
+                                                      R.tensor3(z0), im_ptr, out.data_ptr(), ws.data_ptr(),
+                                                      ws.numel(), R.stream_ptr(dev)), "pio_encoder_fwd")
             run()
             # fp16 range guard of the LayerNorm-folded stack (runtime.range_check): the fold is offered for 1024-channel
             # stacks with >= 2048 rows under the single-sweep policies (pio_ln_fold_t)
@@ -317,6 +325,29 @@ class PerceiverIO(nn.Module):
         self._decoder = PerceiverDecoder(query_channels=query_channels, final_project=final_project,
                                          final_project_out_channels=final_project_out_channels,
                                          num_latent_channels=num_latent_channels, **perceiver_decoder_kwargs)
+        # Opt-in (None = decode every query row, as the reference does): a slice of query rows to decode.  Decoder rows
+        # are independent, so a postprocessor that keeps only some rows (ClassificationPostprocessor: row 0,
+        # postprocessors.py:180-187) gets the same values from the rows alone -- ClassificationPerceiver(
+        # decode_row0_only=True) sets slice(0, 1) and skips 999 / 1000 of the decoder's work.
+        self.decoder_query_rows = None
+
+    # Fused preprocessing hand-off (on by default): a single image modality whose network input is [conv features |
+    # batch-invariant Fourier / learned position table] reaches the encoder as those two arrays
+    # (ImagePreprocessor.forward_split -> PerceiverEncoder.forward((features, table), ...)).  Applies when nothing else
+    # needs the concatenated array: no channel padding, no token masking, queries that do not read the inputs.
+    split_encoder_input = True
+
+    def _split_input(self, inputs, pos):
+        mp = self._multi_preprocessor
+        if (pos is not None or mp._preprocessors is None or list(mp._preprocessors.keys()) != ["__default"]
+                or mp.padding_embeddings is not None or mp._mask_probs is not None):
+            return None
+        prep = mp._preprocessors["__default"]
+        if not hasattr(prep, "forward_split") or not inputs["__default"].is_cuda:
+            return None
+        if any(getattr(q, "_concat_preprocessed_input", False) for q in self._output_queries.values()):
+            return None
+        return prep.forward_split(inputs["__default"])
 
     def decoder_query(self, inputs, modality_sizes, inputs_without_pos=None, subsampled_points=None):
         per_mod = restructure(modality_sizes, inputs)
@@ -345,10 +376,26 @@ class PerceiverIO(nn.Module):
         multi-GPU form for batches smaller than the world (optical flow).  Needs an initialised process group."""
         if type(inputs) is torch.Tensor:
             inputs = {"__default": inputs}
-        x, sizes, without_pos = self._multi_preprocessor(inputs, pos=pos)
-        latents0 = self._encoder.latents(x)
-        query, query_sizes = self.decoder_query(x, sizes, without_pos, subsampled_points=subsampled_output_points)
-        latents = self._encoder(x, latents0, input_mask=input_mask)
+        split = self._split_input(inputs, pos) if self.split_encoder_input else None
+        if split is not None:
+            # the encoder input as (features, batch-invariant position table): never concatenated / replicated in HBM
+            feats, table = split
+            sizes, without_pos = {"__default": feats.shape[1]}, {"__default": feats}
+            latents0 = self._encoder.latents(feats)
+            query, query_sizes = self.decoder_query(feats, sizes, without_pos,
+                                                    subsampled_points=subsampled_output_points)
+            latents = self._encoder((feats, table), latents0, input_mask=input_mask)
+        else:
+            x, sizes, without_pos = self._multi_preprocessor(inputs, pos=pos)
+            latents0 = self._encoder.latents(x)
+            query, query_sizes = self.decoder_query(x, sizes, without_pos, subsampled_points=subsampled_output_points)
+            latents = self._encoder(x, latents0, input_mask=input_mask)
+        if self.decoder_query_rows is not None:
+            query = query[:, self.decoder_query_rows]
+            if query_mask is not None:
+                query_mask = query_mask[:, self.decoder_query_rows]
+            assert len(query_sizes) == 1, "decoder_query_rows is defined for a single output modality"
+            query_sizes = {m: query.shape[1] for m in query_sizes}
         if query_shard is not None:
             from .dist import decode_query_sharded
             outputs = decode_query_sharded(self._decoder, query, latents, query_mask, *query_shard)

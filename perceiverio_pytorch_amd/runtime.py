@@ -364,3 +364,50 @@ def layernorm_desc(ln: torch.nn.LayerNorm, keep: list) -> L.LayerNorm:
     w, b = w.contiguous(), b.contiguous()
     keep += [w, b]
     return L.LayerNorm(w.data_ptr(), b.data_ptr(), w.numel(), float(ln.eps))
+
+
+# ------------------------------------------------------------------------------------------------
+# a plain nn.Linear through the C-ABI primitives (pio_layernorm_cast as the operand cast + pio_gemm_nt): used by the
+# I/O plumbing right behind the decoder (tied-embedding vocabulary projection of the language model)
+# ------------------------------------------------------------------------------------------------
+def hip_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], cache: dict) -> torch.Tensor:
+    """y[..., out] = x[..., in] W^T + b on the MI355X under the current precision policy (weights split from level
+    "x2w" on, activations under "x3").  `cache` keeps the packed weight image between calls."""
+    import ctypes as C
+    require_device(x, "hip_linear")
+    lib = L.lib()
+    dev = x.device
+    dtype, wlevel, split = policy_dtype()
+    key = param_key(weight, bias)
+    pk = cache.get("packed")
+    if pk is None or pk[0] != key:
+        pk = (key, PackedLinear(weight, bias, 1, 1, dtype, wlevel >= 2))
+        cache["packed"] = pk
+    lin = pk[1]
+    lead = x.shape[:-1]
+    x3 = as_f32_3d(x.reshape(1, -1, x.shape[-1]))
+    rows, n_out = x3.shape[1], weight.shape[0]
+    tdt = torch.float16 if dtype == L.PIO_DT_F16 else torch.bfloat16
+    x16 = torch.empty((rows, lin.k), dtype=tdt, device=dev)
+    x16lo = torch.empty((rows, lin.k), dtype=tdt, device=dev) if split else None
+    out = torch.empty((rows, n_out), dtype=torch.float32, device=dev)
+    with on_device(dev):
+        L.check(lib.pio_layernorm_cast(tensor3(x3), None, x16.data_ptr(), x16lo.data_ptr() if split else None, lin.k,
+                                       dtype, stream_ptr(dev)), "pio_layernorm_cast")
+        g = L.Gemm()
+        g.A, g.B = x16.data_ptr(), lin.hi.data_ptr()
+        g.A_lo = x16lo.data_ptr() if split else None
+        g.B_lo = lin.lo.data_ptr() if lin.lo is not None else None
+        g.C = out.data_ptr()
+        g.M, g.N, g.K = rows, n_out, lin.k
+        g.lda = g.ldb = lin.k
+        g.ldc = n_out
+        g.batch = g.nh = 1
+        g.bias = lin.bias.data_ptr()
+        g.bias_mode = 1
+        g.alpha = 1.0
+        g.out_f32 = 1
+        g.n_store = n_out
+        g.dtype = dtype
+        L.check(lib.pio_gemm_nt(C.byref(g), stream_ptr(dev)), "pio_gemm_nt")
+    return forward_only(out.reshape(lead + (n_out,)), x, weight, bias)

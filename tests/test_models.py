@@ -168,3 +168,67 @@ def test_model_outputs_match_reference(name, policy):
             _close(out[:, 640:704], g["out_tail"], name + " tail", tol, absmax=g["out_absmax"])
         else:
             _close(model(ins[0]), g["out"], name, tol)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("policy", ["fp16", "fp16x2w", "fp16x3"])
+def test_classifier_row0_only_decoder_matches_full_decoder(policy):
+    """ClassificationPerceiver(decode_row0_only=True) decodes 1 of the 1000 query rows (the one the postprocessor
+    keeps): same logits as the all-rows path (rows are independent) and as the reference golden."""
+    dev = torch.device("cuda:0")
+    name = "model_classify_conv"
+    g = load(name)
+    model = _load_generated(build(name), g, dev)
+    model.precision_policy = policy
+    x = torch.from_numpy(model_inputs(name)[0]).to(dev)
+    with torch.inference_mode():
+        y_full = model(x)
+        model.decode_row0_only = True
+        assert model.perceiver.decoder_query_rows == slice(0, 1)
+        y_row0 = model(x)
+    assert y_row0.shape == y_full.shape == (2, 1000)
+    _close(y_row0, g["out"], f"row-0 decoder vs golden [{policy}]", TOL if policy != "fp16x3" else 1e-4)
+    _close(y_row0, y_full.cpu().numpy(), f"row-0 decoder vs all rows [{policy}]", 2e-4 if policy != "fp16x3" else 1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("policy", ["fp16x2w", "fp16x3"])
+def test_tied_embedding_projection_runs_in_hip(policy):
+    """EmbeddingPostprocessor (postprocessors.py:25-34) through pio_gemm_nt against the torch matmul it replaces."""
+    import perceiverio_pytorch_amd as P
+    from perceiverio_pytorch_amd.io_processors import EmbeddingPostprocessor
+    from perceiverio_pytorch_amd.runtime import precision
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    emb = torch.nn.Embedding(262, 768)
+    with torch.no_grad():
+        emb.weight.copy_(0.3 * torch.randn(262, 768, generator=g))
+    post = EmbeddingPostprocessor(emb)
+    with torch.no_grad():
+        post.bias.copy_(0.1 * torch.randn(262, generator=g))
+    post = post.to(dev)
+    x = torch.randn(3, 77, 768, generator=g).to(dev)
+    with torch.inference_mode(), precision(policy):
+        y = post(x)
+    ref = (x.double().reshape(-1, 768) @ emb.weight.double().to(dev).T + post.bias.double()).reshape(3, 77, 262)
+    _close(y, ref.cpu().numpy(), f"tied-embedding projection [{policy}]", 1e-3 if policy != "fp16x3" else 1e-5)
+
+
+@pytest.mark.gpu
+def test_split_encoder_input_is_bit_identical_to_the_concatenated_one():
+    """ImageNet conv preprocessing: the encoder fed with (64 conv features, one [3136, 258] Fourier table)
+    (pio_encoder_fwd_split / pio_layernorm_cast_cat) gives the logits of the materialised [B, 3136, 322] hand-off bit
+    for bit (same LayerNorm arithmetic, same lane <-> channel mapping), and the reference golden within 1e-3."""
+    dev = torch.device("cuda:0")
+    name = "model_classify_conv"
+    g = load(name)
+    model = _load_generated(build(name), g, dev)
+    model.precision_policy = "fp16x2w"
+    x = torch.from_numpy(model_inputs(name)[0]).to(dev)
+    assert model.perceiver.split_encoder_input and model.perceiver._split_input({"__default": x}, None) is not None
+    with torch.inference_mode():
+        y_split = model(x)
+        model.perceiver.split_encoder_input = False
+        y_cat = model(x)
+    assert torch.equal(y_split, y_cat)
+    _close(y_split, g["out"], "split encoder input vs golden", TOL)

@@ -997,3 +997,34 @@ def test_fold_on_adversarial_rows(dev, kind):
     e_fold, e_plain = _errs(outs["fold"], ref), _errs(outs["plain"], ref)
     print(f"{kind}: fold relL2={e_fold[0]:.2e} max={e_fold[1]:.2e} | un-folded relL2={e_plain[0]:.2e} max={e_plain[1]:.2e}")
     assert e_fold[0] <= TOL and e_fold[1] <= TOL, (kind, e_fold, e_plain)
+
+
+def test_layernorm_cast_cat_equals_layernorm_of_concatenation(dev):
+    """pio_layernorm_cast_cat([x1 | table]) == pio_layernorm_cast(cat(x1, table)) bit for bit, and the oracle's
+    LayerNorm of the concatenated row within 16-bit rounding."""
+    import perceiverio_pytorch_amd as P
+    from perceiverio_pytorch_amd import _lib as L, runtime as R
+    lib = P.lib()
+    rng = np.random.default_rng(9)
+    B, T, C1, C2 = 3, 50, 64, 258
+    x1 = rng.standard_normal((B, T, C1)).astype(np.float32)
+    tab = rng.standard_normal((1, T, C2)).astype(np.float32)
+    gamma = (1 + 0.1 * rng.standard_normal(C1 + C2)).astype(np.float32)
+    beta = (0.1 * rng.standard_normal(C1 + C2)).astype(np.float32)
+    cp = R.pad8(C1 + C2)
+    t1, t2, tg, tb = _t(x1, dev), _t(tab, dev), _t(gamma, dev), _t(beta, dev)
+    cat = torch.cat([t1, t2.expand(B, T, C2)], dim=-1).contiguous()
+    ln = L.LayerNorm(tg.data_ptr(), tb.data_ptr(), C1 + C2, 1e-5)
+    ya = torch.empty((B * T, cp), dtype=torch.float16, device=dev)
+    yb = torch.empty_like(ya)
+    la, lb = torch.empty_like(ya), torch.empty_like(ya)
+    s = R.stream_ptr(dev)
+    L.check(lib.pio_layernorm_cast_cat(R.tensor3(t1), R.tensor3(t2), ln, ya.data_ptr(), la.data_ptr(), cp,
+                                       L.PIO_DT_F16, s), "cat")
+    L.check(lib.pio_layernorm_cast(R.tensor3(cat), ln, yb.data_ptr(), lb.data_ptr(), cp, L.PIO_DT_F16, s), "plain")
+    torch.cuda.synchronize()
+    assert torch.equal(ya, yb) and torch.equal(la, lb)
+    ref = O.layer_norm(np.concatenate([x1, np.broadcast_to(tab, (B, T, C2))], -1).astype(np.float64),
+                       gamma.astype(np.float64), beta.astype(np.float64))
+    got = (ya.float() + la.float()).cpu().numpy().reshape(B, T, cp)
+    assert np.abs(got[..., :C1 + C2] - ref).max() <= 2e-6 and (got[..., C1 + C2:] == 0).all()
