@@ -27,6 +27,7 @@ Rank 0 prints ONE JSON line.  Extra objects:
   parity       -- in-run check of the benchmarked policy against REFERENCE goldens (gate 1e-3): for imagenet the
                   B = 4 golden, whose 2048 latent rows take the same LayerNorm-fold path as the timed batch
   class_default_policy -- (imagenet) the same step under the class-default policy of ClassificationPerceiver
+  margin_2x_policy     -- (imagenet) the same step under fp16x2s, the fastest policy that meets 1e-3 with a 2x margin
 """
 from __future__ import annotations
 
@@ -412,7 +413,8 @@ def main():
         if name == "imagenet":
             fold_on = lib.pio_ln_fold_enable(1)            # (returns the previous setting: read it and put it back)
             lib.pio_ln_fold_enable(fold_on)
-            parity["layernorm_fold"] = bool(fold_on) and policy in ("fp16", "bf16")
+            # (the fold is offered under every policy with single-sweep ACTIVATIONS: fp16 / x2s / x2w and bf16 likewise)
+            parity["layernorm_fold"] = bool(fold_on) and not policy.endswith("x3")
         if not parity["ok"]:
             raise SystemExit(f"parity gate failed for policy {policy}: {parity}")
 
@@ -460,6 +462,7 @@ def main():
 
         stages = None
         class_default = None
+        robust = None
         if name == "imagenet" and not args.no_extras:
             # ---- per-stage timing of the three hot-path stages (HIP events on the launch stream) ----
             pio = model.perceiver
@@ -504,13 +507,18 @@ def main():
             # ---- choosing a policy)
             from perceiverio_pytorch_amd.models import DEFAULT_POLICY
             dflt = DEFAULT_POLICY["ClassificationPerceiver"]
-            if dflt != policy and not args.hot_path_only:
-                model.precision_policy = dflt
-                el2 = timed_region(2, max(3, steps // 2))
-                model.precision_policy = policy
+            other = {}
+            for pol in ([dflt, "fp16x2s"] if not args.hot_path_only else []):
+                if pol == policy or pol in other:
+                    continue
+                model.precision_policy = pol
                 n2 = max(3, steps // 2)
-                class_default = {"policy": dflt, "value": world * B * n2 / el2, "unit": "samples/s",
-                                 "ms_per_step": el2 / n2 * 1e3}
+                el2 = timed_region(2, n2)
+                other[pol] = {"policy": pol, "value": world * B * n2 / el2, "unit": "samples/s",
+                              "ms_per_step": el2 / n2 * 1e3}
+            model.precision_policy = policy
+            class_default = other.get(dflt)
+            robust = other.get("fp16x2s")
 
     ms_per_step = elapsed / steps * 1e3
     samples_per_step = B if (name == "flow") else world * B
@@ -571,6 +579,10 @@ def main():
         out["stages"] = stages
     if class_default is not None:
         out["class_default_policy"] = class_default
+    if robust is not None:
+        # weights of proj_v and final as (hi, lo) pairs: 4.8e-4 / 5.3e-4 against the reference on the B = 4 golden --
+        # the policy to quote if the 1e-3 bar must hold with a 2x margin (the headline policy sits at 7.3e-4 / 8.4e-4)
+        out["margin_2x_policy"] = robust
     if rank == 0 and world == 1:
         nb = args.cpu_sample if args.cpu_sample is not None else {"imagenet": 8, "language": 4, "flow": 1,
                                                                   "multimodal": 1}[name]

@@ -61,6 +61,8 @@ typedef struct pio_linear_t {
     const float *bias; /* [n_pad] zero padded, or NULL */
     int32_t n;         /* padded output features  (multiple of 8)  */
     int32_t k;         /* padded input features   (multiple of 8)  */
+    int32_t lo_row0;   /* w_lo holds rows [lo_row0, n) only (a stacked q|k|v image whose v part alone is split);
+                          0 = every row.  Must be a multiple of 256; honoured by the wide GEMM kernel only.          */
 } pio_linear_t;
 
 /* nn.LayerNorm(c) (transformer_primitives.py:270-271, 365-367) */
@@ -247,6 +249,9 @@ typedef struct pio_gemm_t {
      * both set, C may be NULL: the fp32 result is then not written at all. */
     void *X16_lo;
     const void *R16_hi, *R16_lo;
+    /* B_lo holds rows (= output columns) [b_lo_n0, N) only: the extra sweep C += A B_lo^T runs for those columns
+     * alone.  0 = all rows.  Multiple of 256; kernel gemm_nt_wide only (else PIO_E_SHAPE). */
+    int32_t b_lo_n0;
 } pio_gemm_t;
 int pio_gemm_nt(const pio_gemm_t *g, void *stream);
 

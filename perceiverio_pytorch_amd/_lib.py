@@ -27,7 +27,8 @@ class PioError(RuntimeError):
 
 
 class Linear(C.Structure):
-    _fields_ = [("w_hi", C.c_void_p), ("w_lo", C.c_void_p), ("bias", C.c_void_p), ("n", C.c_int32), ("k", C.c_int32)]
+    _fields_ = [("w_hi", C.c_void_p), ("w_lo", C.c_void_p), ("bias", C.c_void_p), ("n", C.c_int32), ("k", C.c_int32),
+                ("lo_row0", C.c_int32)]
 
 
 class LayerNorm(C.Structure):
@@ -78,7 +79,7 @@ class Gemm(C.Structure):
                 ("dtype", C.c_int32),
                 ("X16", C.c_void_p), ("ld16", C.c_int64), ("row_part", C.c_void_p), ("ln_part", C.c_void_p),
                 ("ln_c", C.c_void_p), ("ln_eps", C.c_float),
-                ("X16_lo", C.c_void_p), ("R16_hi", C.c_void_p), ("R16_lo", C.c_void_p)]
+                ("X16_lo", C.c_void_p), ("R16_hi", C.c_void_p), ("R16_lo", C.c_void_p), ("b_lo_n0", C.c_int32)]
 
 
 # name -> (restype, argtypes); must list EVERY function declared in include/pio_hip.h

@@ -95,6 +95,7 @@ static int linear_fwd(const pio_linear_t &lin_plain, int dtype, Pair x, int64_t 
     g.A_lo = x.lo;
     g.B = lin.w_hi;
     g.B_lo = lin.w_lo;
+    g.b_lo_n0 = lin.w_lo ? lin.lo_row0 : 0;
     g.C = y;
     g.C_lo = y_lo;
     g.M = (int)rows;
@@ -211,7 +212,11 @@ static int attention_core(const pio_attention_t &a, Pair xq, bool q_bcast, Pair 
     //    scratch regions adjacent so that they form one [rows, 3*H*128] matrix.
     {
         const size_t third = (size_t)B * Tq * hdk * 2;
-        const bool fuse_qkv = a.qkv.w_hi && !a.qkv.w_lo && !a.act_split && !q_bcast && xq.hi == xk.hi &&
+        // (a q|k|v image whose V rows alone carry a lo half -- policies "x2s" / "x2w" -- is taken only inside the
+        //  LayerNorm fold, where the wide GEMM kernel, which honours pio_linear_t.lo_row0, is guaranteed)
+        const pio_linear_t &qkv_used = (fold_in && fold_in->in_part) ? *fold_in->w : a.qkv;
+        const bool qkv_lo_ok = !qkv_used.w_lo || (fold_in && fold_in->in_part && qkv_used.lo_row0 == 2 * hdk);
+        const bool fuse_qkv = a.qkv.w_hi && qkv_lo_ok && !a.act_split && !q_bcast && xq.hi == xk.hi &&
                               xk.hi == xv.hi && Tq == Tk && a.dkp == 128 && a.dvp == 128 && a.qkv.n == 3 * hdk &&
                               !kv_mask && !q_mask && !full_mask && !attention_bias && !probs_out &&
                               (char *)w.k16.hi == (char *)w.q16.hi + third &&
@@ -481,9 +486,12 @@ static int self_attention_run(const pio_self_attention_t &sa, const pio_tensor3_
         return PIO_E_SHAPE;  // residual adds need matching widths (the reference raises a RuntimeError)
     // LayerNorm fold: 1024-channel contiguous rows, single-sweep operands, the fused q|k|v form, enough rows for the
     // 256x256-tile kernel to fill the chip, nothing that needs the score matrix
+    // (weights may be (hi, lo) pairs -- policies "x2s" / "x2w": the wide kernel runs a second K sweep against the lo
+    //  image; of the stacked q|k|v image only the V rows may have one.  Activations single-sweep.)
     const bool fold = ln_fold_enabled() && p.x16b && x.C == 1024 && rows >= 2048 && x.stride_t == x.C &&
                       (B == 1 || x.stride_b == (int64_t)N * x.C) && !sa.attn.act_split && !sa.mlp.act_split &&
-                      sa.attn.qkv.w_hi && !sa.attn.qkv.w_lo && !sa.mlp.fc1.w_lo && !sa.mlp.fc2.w_lo && !sa.attn.o.w_lo &&
+                      sa.attn.qkv.w_hi && (!sa.fold.qkv.w_lo || sa.fold.qkv.lo_row0 == 2 * sa.attn.heads * sa.attn.dkp) &&
+                      (!sa.fold.fc1.w_lo || sa.fold.fc1.lo_row0 == 0) &&
                       sa.attn.dkp == 128 && sa.attn.dvp == 128 && sa.fold.qkv.n == sa.attn.qkv.n &&
                       sa.fold.qkv.k == 1024 && sa.fold.fc1.k == 1024 && sa.fold.fc1.n == sa.mlp.fc1.n &&
                       sa.mlp.dtype == sa.attn.dtype && !kv_mask && !q_mask && !full_mask && !attention_bias &&

@@ -284,6 +284,8 @@ int gemm_nt_launch(const pio_gemm_t &g, hipStream_t s) {
     p.X16 = g.X16; p.ld16 = g.ld16; p.row_part = g.row_part;
     p.ln_part = g.ln_part; p.ln_c = g.ln_c; p.ln_eps = g.ln_eps;
     p.X16_lo = g.X16_lo; p.R16_hi = g.R16_hi; p.R16_lo = g.R16_lo;
+    p.lo_n0 = g.B_lo ? g.b_lo_n0 : 0;
+    if (g.b_lo_n0 && (!g.B_lo || g.A_lo)) return PIO_E_ARG;
     p.n_store = g.n_store > g.N ? g.n_store : g.N;
     if (g.C && p.n_store > g.ldc) return PIO_E_SHAPE;
     p.tiles_n = (p.n_store + BN - 1) / BN;
@@ -356,6 +358,7 @@ int gemm_nt_launch(const pio_gemm_t &g, hipStream_t s) {
                 return launch_status();
             }
         }
+        if (p.lo_n0) return PIO_E_SHAPE;  // (a partial B_lo is a gemm_nt_wide feature)
         // Persistent 256x128 streaming kernel (epilogue of tile j hidden behind the MFMAs of tile j+1): deep-K flat
         // problems with about two or more tiles per CU (with fewer there is nothing to hide an epilogue behind and
         // the 256x256 tile's lower operand traffic wins).  Override 1 forces it wherever it is legal.

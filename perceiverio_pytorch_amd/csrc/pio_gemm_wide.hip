@@ -167,16 +167,21 @@ __global__ __launch_bounds__(256) void gemm_nt_wide(const GemmParams p, int tile
             tn = id - tm * tiles_n;
         }
     };
-    const int nph = p.K / W_BK;  // >= 4 and even (launcher)
+    // K slices per tile: K / 32 (>= 4 and even: launcher); with a second weight image (p.npass == 2: C += A B_lo^T, the
+    // rounding residual of the weights) the tiles whose columns have one run the K range twice, the second time
+    // against B_lo -- same A slices, same accumulators.  Columns below p.lo_n0 (a multiple of 256) have no B_lo.
+    const int nphK = p.K / W_BK;
+    auto nph_of = [&](int tn) { return (p.npass == 2 && tn * W_BN >= p.lo_n0) ? 2 * nphK : nphK; };
 
     // ---- DMA side: a 1-KiB piece = 16 rows x 64 B; wave w owns A pieces 4w..4w+3 and B pieces 4w..4w+3 of a slice.
     const int prow = lane >> 2;
     const int qsrc = (lane & 3) ^ ((0x78 >> (2 * ((prow >> 2) & 3))) & 3);  // source chunk of LDS position lane & 3
-    int dj = 0, dph = 0, dslot = 0;
+    int dj = 0, dph = 0, dslot = 0, dnph = nphK;
     uint32_t voa[4], vob[4];  // per-lane byte offsets (row, chunk) inside A / B (< 2^32: launcher)
     auto dma_tile = [&](int j) {
         int tm, tn;
         tile_mn(j, tm, tn);
+        dnph = nph_of(tn);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             int gm = tm * W_BM + wave * 64 + i * 16 + prow;
@@ -198,8 +203,9 @@ __global__ __launch_bounds__(256) void gemm_nt_wide(const GemmParams p, int tile
     int istep = 0, ibo = 0;
     auto issue_begin = [&]() {
         if (dj < ntl) {
-            ia = (const char *)((const T *)p.A + dph * W_BK);
-            ib = (const char *)((const T *)p.B + dph * W_BK);
+            const int kph = dph < nphK ? dph : dph - nphK;  // second sweep: the same A slices against B_lo
+            ia = (const char *)((const T *)p.A + kph * W_BK);
+            ib = (const char *)((const T *)p.B + (dph < nphK ? 0 : p.dB1) + kph * W_BK);
             isb = smem + dslot * W_STAGE + wave * 4096;
             istep = 1024;
             ibo = W_AB;
@@ -221,7 +227,7 @@ __global__ __launch_bounds__(256) void gemm_nt_wide(const GemmParams p, int tile
     };
     auto issue_end = [&]() {
         dslot = (dslot + 1) & 3;
-        if (dj < ntl && ++dph == nph) {
+        if (dj < ntl && ++dph == dnph) {
             dph = 0;
             if (++dj < ntl) dma_tile(dj);
         }
@@ -351,12 +357,14 @@ __global__ __launch_bounds__(256) void gemm_nt_wide(const GemmParams p, int tile
     {
 #pragma unroll 1
     for (int j = 0; j < ntl; ++j) {
+        int nph;
         {
             int tm, tn;
             tile_mn(j, tm, tn);
             o_m = tm * W_BM + wm * 128 + fr;
             o_n0 = tn * W_BN + wn * 128;
             o_n = o_n0 + fq * 8;
+            nph = nph_of(tn);
         }
         // stores of one epilogue per wave (a lower bound is enough once it exceeds the counter's ceiling) + the DMAs
         // of the bias / c rows at the head of the tile's first phase
@@ -625,7 +633,10 @@ static int wide_grid(int64_t total) {
 }
 
 bool gemm_wide_ok(const GemmParams &p, int batch) {
-    if (batch != 1 || p.npass != 1) return false;
+    if (batch != 1 || p.npass > 2) return false;
+    // a second sweep against B_lo only (weights as hi + lo, single activations), from a 256-aligned column on
+    if (p.npass == 2 && (p.dA1 != 0 || p.dB1 == 0 || p.lo_n0 < 0 || (p.lo_n0 % W_BN))) return false;
+    if (p.npass == 1 && p.lo_n0 != 0) return false;
     if (p.K < 4 * W_BK || (p.K % (2 * W_BK))) return false;
     if (p.C_lo || (p.act != 0 && p.act != 1)) return false;
     if (p.out_f32 && (p.act != 0 || (p.C && (p.ldc & 3)))) return false;

@@ -267,10 +267,16 @@ class PackedLinear:
 
 class PackedStack:
     """Several nn.Linear with equal in_features stacked along the output rows in ONE packed image
-    (e.g. proj_q | proj_k, consumed by a single GEMM when both read the same input)."""
+    (e.g. proj_q | proj_k, consumed by a single GEMM when both read the same input).  `two_pass` is a bool (every part)
+    or one bool per part: only a SUFFIX of the parts may carry a lo image (q | k | v with v alone split); the
+    descriptor's lo_row0 then names the first row that has one."""
 
-    def __init__(self, pairs, row_heads: int, dtype: int, two_pass: bool):
+    def __init__(self, pairs, row_heads: int, dtype: int, two_pass):
         lib = L.lib()
+        flags = [bool(two_pass)] * len(pairs) if isinstance(two_pass, bool) else [bool(f) for f in two_pass]
+        if any(a and not b for a, b in zip(flags, flags[1:])):
+            raise ValueError("only a suffix of the stacked linears may be split")
+        two_pass = any(flags)
         w0 = pairs[0][0]
         require_device(w0, "pack_linear")
         dev = w0.device
@@ -282,19 +288,25 @@ class PackedStack:
         self.hi = torch.empty((self.n, self.k), dtype=tdt, device=dev)
         self.lo = torch.empty((self.n, self.k), dtype=tdt, device=dev) if two_pass else None
         self.bias = torch.empty((self.n,), dtype=torch.float32, device=dev)
+        if self.lo is not None and not all(flags):
+            self.lo.zero_()          # rows without a lo half are never read; keep them defined
         r0 = 0
-        for (w, b), nr in zip(pairs, rows):
+        lo_row0 = 0
+        for (w, b), nr, fl in zip(pairs, rows, flags):
             if w.shape[1] != inn:
                 raise ValueError("stacked linears need equal in_features")
             wf = w.detach().float().contiguous()
             bf = b.detach().float().contiguous() if b is not None else None
             L.check(lib.pio_pack_linear(wf.data_ptr(), bf.data_ptr() if bf is not None else None, w.shape[0], inn,
                                         inn, row_heads, 1, self.hi.data_ptr(),
-                                        self.lo.data_ptr() if two_pass else None, self.bias.data_ptr(), r0, self.k,
+                                        self.lo.data_ptr() if fl else None, self.bias.data_ptr(), r0, self.k,
                                         dtype, stream_ptr(dev)), "pio_pack_linear")
+            if not fl:
+                lo_row0 = r0 + nr
             r0 += nr
+        self.lo_row0 = lo_row0 if two_pass else 0
         self.desc = L.Linear(self.hi.data_ptr(), self.lo.data_ptr() if two_pass else None, self.bias.data_ptr(),
-                             self.n, self.k)
+                             self.n, self.k, self.lo_row0)
 
 
 def _version_of(p: torch.Tensor) -> int:

@@ -145,12 +145,13 @@ class Attention(_HipModule):
                                H, dtype, two)
             d.qk = qk.desc
             keep.append(qk)
-            # q | k | v in one image: usable when no projection needs a second sweep (plain 1-sweep policy) and
-            # the fused attention kernel can read V row-major (per-head widths 128 / 128)
-            if (wlevel == 0 and self.proj_v.in_features == self.proj_q.in_features and R.pad8(dk) == 128
-                    and R.pad8(dv) == 128):
+            # q | k | v in one image when the fused attention kernel can read V row-major (per-head widths 128 / 128).
+            # Under "x2s" / "x2w" the V rows alone carry a lo image (pio_linear_t.lo_row0): the wide GEMM kernel runs
+            # its second K sweep for those columns only -- the library takes such an image inside the LayerNorm fold.
+            if (wlevel <= 2 and not two and self.proj_v.in_features == self.proj_q.in_features and R.pad8(dk) == 128
+                    and R.pad8(dv) == 128 and (wlevel == 0 or (2 * H * 128) % 256 == 0)):
                 qkv = R.PackedStack([(self.proj_q.weight, self.proj_q.bias), (self.proj_k.weight, self.proj_k.bias),
-                                     (self.proj_v.weight, self.proj_v.bias)], H, dtype, False)
+                                     (self.proj_v.weight, self.proj_v.bias)], H, dtype, [False, False, wlevel >= 1])
                 d.qkv = qkv.desc
                 keep.append(qkv)
         return d, keep
@@ -287,7 +288,7 @@ class SelfAttention(_HipModule):
         Offered for 1024-channel blocks under the single-sweep policies; the library decides per call."""
         dtype, wlevel, split = R.policy_dtype()
         att, mlp = self.attention, self.mlp
-        if (wlevel != 0 or split or self._in_channels != 1024 or not a.qkv.w_hi
+        if (wlevel > 2 or split or self._in_channels != 1024 or not a.qkv.w_hi
                 or mlp.fc1.in_features != 1024 or att.proj_q.in_features != 1024):
             return
         with torch.no_grad():
@@ -300,11 +301,13 @@ class SelfAttention(_HipModule):
                 return (w * g[None, :]).contiguous(), (w @ b + bias).contiguous()
 
             H = att._num_heads
+            # (the split levels of the un-folded descriptors: proj_v from "x2s" on, fc1 from "x2w" on)
             qkv = R.PackedStack([folded(att.proj_q, g1, b1), folded(att.proj_k, g1, b1), folded(att.proj_v, g1, b1)],
-                                H, dtype, False)
-            fc1 = R.PackedLinear(*folded(mlp.fc1, g2, b2), 1, 1, dtype, False)
-            qkv_c = qkv.hi.float().sum(1).contiguous()
-            fc1_c = fc1.hi.float().sum(1).contiguous()
+                                H, dtype, [False, False, wlevel >= 1])
+            fc1 = R.PackedLinear(*folded(mlp.fc1, g2, b2), 1, 1, dtype, wlevel >= 2)
+            # c[n] = sum_k of the packed weights the GEMM actually multiplies with: hi (+ lo where there is one)
+            qkv_c = (qkv.hi.float() + (qkv.lo.float() if qkv.lo is not None else 0)).sum(1).contiguous()
+            fc1_c = (fc1.hi.float() + (fc1.lo.float() if fc1.lo is not None else 0)).sum(1).contiguous()
         d.fold = L.LnFold(qkv.desc, qkv_c.data_ptr(), fc1.desc, fc1_c.data_ptr())
         keep.extend([qkv, fc1, qkv_c, fc1_c])
 
