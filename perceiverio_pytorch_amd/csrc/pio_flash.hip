@@ -14,6 +14,8 @@
 //     XOR swizzle applied on the source address and on the ds_read side (conflict-free K reads, 2-way V^T reads).
 //   * V is consumed K-contiguous (V^T [dv][keys]), which is exactly what the V projection GEMM writes.
 //   * online softmax in base 2 (scale folded into the exponent constant), fp32 statistics and accumulators.
+#include <stdlib.h>
+
 #include "pio_internal.h"
 
 namespace pio {
@@ -269,6 +271,234 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void flash_attn_kernel(co
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same attention for the hot shape of the latent self-attend stack (128-wide heads, V row-major out of the fused
+// q|k|v GEMM, 256-query workgroups of 8 waves = 2 per SIMD) with the two waves of a SIMD STAGGERED by half a key tile.
+// In flash_attn_kernel all eight waves move through S = K Q^T, the softmax and O += P V together: matrix pipe, VALU
+// and LDS take turns (stamps: ~5.1 k cycles per 64-key tile against 2 k of MFMA time).  Here waves 0-3 ("A") run
+// [S(k), softmax(k), PV(k)] between two barriers while waves 4-7 ("B") run [PV(k-1), S(k), softmax(k)]: A's softmax
+// (VALU) overlaps B's S (MFMA), A's PV overlaps B's softmax; only A's S and B's PV meet on the matrix pipe.  ONE
+// barrier per tile, passed by A at the start of tile k and by B between softmax(k-1) and PV(k-1): the V tile of k-1 is
+// still being read by B when tile k+1 is staged, hence THREE K/V stages.  Both groups issue their share of tile
+// k + 1's LDS-DMA pieces right behind barrier k and wait for them before barrier k + 1.
+// ---------------------------------------------------------------------------------------------------------------
+template <int DT>
+__global__ __launch_bounds__(512, 1) void flash_attn_stag_kernel(const FlashParams p) {
+    typedef typename Op<DT>::T T;
+    typedef typename Op<DT>::V8 V8;
+    typedef typename Op<DT>::V4 V4;
+    typedef short tr4 __attribute__((__vector_size__(4 * sizeof(short))));
+    constexpr int DK = 128, DV = 128, NW = 8;
+    constexpr int KT = 64;
+    constexpr int K_TILE = KT * DK * 2, V_TILE = DV * KT * 2;
+    constexpr int STG = K_TILE + V_TILE;
+    constexpr int KCPR = DK / 8, KRPB = 16 / KCPR;
+    constexpr int K_PIECES = K_TILE / 1024, V_PIECES = V_TILE / 1024;
+    constexpr int NDT = DV / 32, NQS = DK / 16;
+    __shared__ __attribute__((aligned(16))) char smem[3 * STG];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r32 = lane & 31, hh = lane >> 5;
+    int bid = blockIdx.x;
+    const int nblk = gridDim.x;
+    if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
+    const int qt = bid % p.nqt, bh = bid / p.nqt;
+    const int b = bh / p.H, h = bh % p.H;
+    const int q0 = qt * (NW * 32) + wave * 32;
+
+    const T *Qg = (const T *)p.Q + b * p.sQb + (int64_t)h * DK;
+    const T *Kg = (const T *)p.K + b * p.sKb + (int64_t)h * DK;
+    const T *Vg = (const T *)p.VT + b * p.sVb + (int64_t)h * DV;
+
+    V8 qf[NQS];
+    {
+        int q = q0 + r32;
+        q = q < p.Tq ? q : p.Tq - 1;
+        const T *qrow = Qg + (int64_t)q * p.ldq + 8 * hh;
+#pragma unroll
+        for (int s = 0; s < NQS; ++s) qf[s] = *(const V8 *)(qrow + 16 * s);
+    }
+    const int ntiles = (p.Tk + KT - 1) / KT;
+
+    auto stage = [&](int kt) {  // this wave's share (1 / 8) of tile kt's pieces into stage kt % 3
+        char *kb = smem + (kt % 3) * STG;
+        char *vb = kb + K_TILE;
+        const int k0 = kt * KT;
+        for (int pc = wave; pc < K_PIECES; pc += NW) {
+            const int row = pc * (64 / KCPR) + lane / KCPR;
+            const int slot = lane % KCPR;
+            const int c = slot ^ ((row / KRPB) & (KCPR - 1));
+            int key = k0 + row;
+            key = key < p.Tk ? key : p.Tk - 1;
+            const T *src = Kg + (int64_t)key * p.ldk + c * 8;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(kb + pc * 1024), 16, 0, 0);
+        }
+        for (int pc = wave; pc < V_PIECES; pc += NW) {  // row-major V tile [64 keys][128]: a piece = 4 key rows
+            const int row = pc * 4 + (lane >> 4);
+            const int slot = lane & 15;
+            const int c = slot ^ (((row & 3) << 2) | ((row >> 2) & 3));
+            int key = k0 + row;
+            key = key < p.Tk ? key : p.Tk - 1;
+            const T *src = Vg + (int64_t)key * p.ldvt + c * 8;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(vb + pc * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x16 oacc[NDT];
+#pragma unroll
+    for (int i = 0; i < NDT; ++i)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) oacc[i][j] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    f32x16 sacc[2];
+    V8 pf[2][2];
+
+    int k_off[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) k_off[t] = (32 * t + r32) * (DK * 2);
+    const int k_swz = (r32 / KRPB) & (KCPR - 1);
+
+    auto phase_s = [&](int kt) {  // S^T = K Q^T for the two 32-key halves of tile kt
+        const char *kb = smem + (kt % 3) * STG;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) sacc[t][j] = 0.f;
+#pragma unroll
+            for (int s = 0; s < NQS; ++s) {
+                const int chunk = (2 * s + hh) ^ k_swz;
+                const V8 kf = *(const V8 *)(kb + k_off[t] + chunk * 16);
+                sacc[t] = Op<DT>::mfma32(kf, qf[s], sacc[t]);
+            }
+        }
+    };
+    auto phase_softmax = [&](int kt) {  // online softmax of tile kt: sacc -> pf, rescales oacc when a maximum moved
+        const bool tail = (kt == ntiles - 1) && (p.Tk % KT != 0);
+        float mx = -INFINITY;
+        if (tail) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int key = kt * KT + 32 * t + (i & 3) + 8 * (i >> 2) + 4 * hh;
+                    if (key >= p.Tk) sacc[t][i] = -INFINITY;
+                }
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) mx = fmaxf(mx, sacc[t][i]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * p.scale_log2;
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        m_run = m_new;
+        float psum = 0.f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float e = __builtin_amdgcn_exp2f(fmaf(sacc[t][i], p.scale_log2, -m_new));
+                sacc[t][i] = e;
+                psum += e;
+            }
+        l_run = l_run * alpha + psum;
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
+#pragma unroll
+            for (int d = 0; d < NDT; ++d)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) oacc[d][j] *= alpha;
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pf[t][s][j] = Op<DT>::from_f32(sacc[t][8 * s + j]);
+    };
+    auto phase_pv = [&](int kt) {  // O^T += V^T P^T with the row-major V tile of kt read transposed
+        const char *vb = smem + (kt % 3) * STG + K_TILE;
+#pragma unroll
+        for (int d = 0; d < NDT; ++d) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    V4 lo, hi;
+                    const int q4 = (lane & 15) >> 2, p4 = lane & 3, g1 = (lane >> 4) & 1;
+                    const int chunk = d * 4 + 2 * g1 + (p4 >> 1);
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) {
+                        const int key = 32 * t + 16 * s + 8 * jj + 4 * hh + q4;
+                        const int f = (q4 << 2) | ((hh + 2 * jj) & 3);
+                        const char *a = vb + key * 256 + ((chunk ^ f) << 4) + 8 * (p4 & 1);
+                        const tr4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tr4 *)a);
+                        if (jj == 0) lo = __builtin_bit_cast(V4, r);
+                        else hi = __builtin_bit_cast(V4, r);
+                    }
+                    V8 vf;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        vf[j] = lo[j];
+                        vf[4 + j] = hi[j];
+                    }
+                    oacc[d] = Op<DT>::mfma32(vf, pf[t][s], oacc[d]);
+                }
+        }
+    };
+    auto meet = [&]() {  // this wave's pieces have landed; after the barrier everybody's have
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    };
+
+    stage(0);
+    if (wave < 4) {
+        // ---- group A: [barrier k] stage(k+1) S(k) softmax(k) PV(k)
+        for (int kt = 0; kt < ntiles; ++kt) {
+            meet();
+            if (kt + 1 < ntiles) stage(kt + 1);
+            phase_s(kt);
+            phase_softmax(kt);
+            phase_pv(kt);
+        }
+        meet();  // barrier ntiles: group B passes it before its last PV
+    } else {
+        // ---- group B: [barrier 0] stage(1) S(0) softmax(0); then [barrier k] stage(k+1) PV(k-1) S(k) softmax(k)
+        meet();
+        if (1 < ntiles) stage(1);
+        phase_s(0);
+        phase_softmax(0);
+        for (int kt = 1; kt <= ntiles; ++kt) {
+            meet();
+            if (kt + 1 < ntiles) stage(kt + 1);
+            phase_pv(kt - 1);
+            if (kt < ntiles) {
+                phase_s(kt);
+                phase_softmax(kt);
+            }
+        }
+    }
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    const int q = q0 + r32;
+    if (q < p.Tq) {
+        T *orow = (T *)p.O + b * p.sOb + (int64_t)q * p.ldo + (int64_t)h * DV;
+#pragma unroll
+        for (int d = 0; d < NDT; ++d)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                V4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = Op<DT>::from_f32(oacc[d][4 * g4 + j] * inv);
+                *(V4 *)(orow + 32 * d + 8 * g4 + 4 * hh) = o;
+            }
+    }
+}
+
 bool flash_supported(int dkp, int dvp) {
     return (dkp == 128 && dvp == 128) || (dkp == 64 && dvp == 64) || (dkp == 32 && dvp == 32) ||
            (dkp == 32 && dvp == 160);
@@ -299,7 +529,18 @@ int flash_attention_launch(int dtype, int dkp, int dvp, int dk_logical, const vo
         if (dtype == PIO_DT_F16) PIO_FLASH(PIO_DT_F16, DKV, DVV);      \
         else PIO_FLASH(PIO_DT_BF16, DKV, DVV);                         \
     } while (0)
-    if (v_rowmajor && wide) {
+    // A/B switch: env PIO_FLASH_STAGGER=1 selects the staggered kernel.  Measured (B = 32 ImageNet stack, same box):
+    // 65.4 us staggered against 60.9 us lock-step per launch -- the SIMD's issue port, shared by the two waves, is
+    // the limit (per wave and tile ~130 VALU + 32 MFMA + 48 LDS instructions), so re-phasing the waves does not help
+    // and the extra stage / barrier placement costs.  Kept as an experiment, off by default.
+    static const bool stagger = [] {
+        const char *e = getenv("PIO_FLASH_STAGGER");
+        return e && atoi(e) != 0;
+    }();
+    if (v_rowmajor && wide && stagger) {
+        if (dtype == PIO_DT_F16) hipLaunchKernelGGL((flash_attn_stag_kernel<PIO_DT_F16>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((flash_attn_stag_kernel<PIO_DT_BF16>), grid, block, 0, s, p);
+    } else if (v_rowmajor && wide) {
         if (dtype == PIO_DT_F16) hipLaunchKernelGGL((flash_attn_kernel<PIO_DT_F16, 128, 128, true, 8>), grid, block, 0, s, p);
         else hipLaunchKernelGGL((flash_attn_kernel<PIO_DT_BF16, 128, 128, true, 8>), grid, block, 0, s, p);
     } else if (v_rowmajor) {

@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256, (DKL <= 128 && DVS <= 160) ? 2 : 1) void xattn
     typedef typename Op<DT>::V8 V8;
     typedef typename Op<DT>::V4 V4;
     constexpr int KT = 32;                                               // keys per tile
-    constexpr bool PIN = DKL > 128 && DKL <= 512;  // wide heads without spills: one wave per SIMD, pinned register files
+    constexpr bool PIN = DKL > 128;                // wide heads: one wave per SIMD, pinned register files
     constexpr int KP = DKL <= 128 ? 128 : ((DKL + 127) / 128) * 128;     // LDS pitch of a K row, elements
     constexpr int KCH = KP / 8;                                          // 16-byte chunks per K row
     constexpr int K_TILE = KT * KP * 2, V_TILE = DVS * KT * 2;           // bytes
@@ -486,7 +486,7 @@ struct XCfg {
     int dkl, dvs;
 };
 // the kernel instantiations, narrowest first
-constexpr XCfg kCfgs[] = {{32, 96}, {32, 160}, {128, 128}, {352, 192}, {512, 256}, {704, 352}};
+constexpr XCfg kCfgs[] = {{32, 96}, {32, 160}, {128, 128}, {352, 192}, {512, 256}, {704, 256}};
 
 const XCfg *xattn_cfg(int dkp, int dvp) {
     for (const XCfg &c : kCfgs) {
@@ -575,7 +575,7 @@ int xattn_launch(int dtype, int dkp, int dvp, int dk_logical, const void *Q, con
         else if (c->dkl == 128) PIO_XA(128, 128);
         else if (c->dkl == 352) PIO_XA(352, 192);
         else if (c->dkl == 512) PIO_XA(512, 256);
-        else PIO_XA(704, 352);
+        else PIO_XA(704, 256);
 #undef PIO_XA
         if (nsplit > 1) {
             const int64_t total = (int64_t)B * H * Tq * (dvp / 4);
