@@ -69,7 +69,7 @@ CONFIGS = {
                                  num_self_attend_heads=8, encoder_query_residual=True, decoder_heads=8,
                                  decoder_query_residual=False, final_project=False),
                      hot=dict(M=2048, C=768, Q=2048)),
-    "flow": dict(golden="model_flow_full", parity_golden="model_flow_full", batch=1, policy="fp16x3", gflop=1885.5,
+    "flow": dict(golden="model_flow_full", parity_golden="model_flow_full", batch=1, policy="fp16x2w/fp16x3", gflop=1885.5,
                  scaling="strong",
                  metric="samples/sec PerceiverIO fwd (optical flow, 368x496 frame pair, 2048x512 latents, 24 self-attends)",
                  workload="FlowPerceiver: frame pair [1,3,368,496] x2 -> 3x3 patches -> encoder 182528x322->2048x512, "
@@ -78,7 +78,8 @@ CONFIGS = {
                              num_self_attend_heads=16, encoder_query_residual=True, decoder_heads=1,
                              decoder_query_residual=False, final_project=True),
                  hot=dict(M=182528, C=322, Q=182528)),
-    "multimodal": dict(golden="model_multimodal_full", parity_golden="model_multimodal_full", batch=1, policy="fp16x3",
+    "multimodal": dict(golden="model_multimodal_full", parity_golden="model_multimodal_full", batch=1,
+                       policy="fp16x2w/fp16x3",
                        gflop=250.1 + 128 * 57.2, scaling="weak",
                        metric="samples/sec PerceiverIO fwd (multimodal autoencode, 16x224x224 video + audio + label, "
                               "784x512 latents, 128 output chunks)",
@@ -192,7 +193,8 @@ def parity_check(name, model, params, dev, policy):
             acs = audio.shape[1] // model.audio_samples_per_patch // c["n_chunks"]
             sub = {"image": torch.arange(ics * k, ics * (k + 1)), "audio": torch.arange(acs * k, acs * (k + 1)),
                    "label": None}
-            with precision(policy):
+            from perceiverio_pytorch_amd.models import _policy_scope
+            with _policy_scope(model):
                 o = model.perceiver({"image": images, "audio": audio,
                                      "label": torch.zeros((b, model.num_classes), device=dev)},
                                     subsampled_output_points=sub)
@@ -387,7 +389,7 @@ def main():
     from perceiverio_pytorch_amd.dist import all_gather_rows
     lib = P.lib()
     assert lib.pio_arch_ok() == 1, "libpio_hip.so is gfx950-only"
-    P.set_precision_policy(policy)
+    P.set_precision_policy(policy.split("/")[0])      # ("A/B": encoder policy / decoder policy, models.split_policy)
 
     model, params = build_model(name, dev, policy)
     inputs = make_inputs(name, B, rank, dev)               # resident in HBM before the timed region

@@ -127,8 +127,11 @@ static int cast_pair(const pio_tensor3_t &x, const pio_layernorm_t *ln, Pair y, 
 // ------------------------------------------------------------------------------------------------------
 // Upper bound of the materialised score matrix held at once (fp32 scores + 16-bit probabilities are carved for this many
 // (batch, row) slabs): attention over more than this is run sample by sample and, inside a sample, in chunks of query
-// rows -- the optical-flow cross-attends (2048 x 182 528 scores per head: 1.5 GB fp32) never get a 1.5 GB buffer.
-static const int64_t kScoreCapBytes = 256ll << 20;
+// rows.  Only the 3-sweep policies ("x3": split activations) still materialise scores for the wide cross-attends; the
+// optical-flow ones (2048 x 182 528 scores: 1.5 GB fp32 + as much again for the probability pair) then run in two
+// passes of <= 1 GiB.  (A 256 MiB cap was measured too: 8 passes, each P V product with only 6 output tiles of a
+// 182 528-deep K loop -- 96 ms instead of 29 per forward.)
+static const int64_t kScoreCapBytes = 1ll << 30;
 
 struct ScoreChunks {
     int b_chunk;  // samples per pass (>= 1)

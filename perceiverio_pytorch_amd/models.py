@@ -24,8 +24,42 @@ from .position_encoding import PosEncodingType
 # Precision policy each task model runs under unless `model.precision_policy` is changed (None = the global policy of
 # perceiverio_pytorch_amd.set_precision_policy).  The defaults are the fastest policies that meet the 1e-3 parity bar
 # against the reference on that architecture (tests/test_models.py).
-DEFAULT_POLICY = {"ClassificationPerceiver": "fp16x2w", "LanguagePerceiver": "fp16x2w", "FlowPerceiver": "fp16x3",
-                  "MultiModalPerceiver": "fp16x3"}
+# "A/B" = policy A for the encoder (cross-attend + latent stack), B for the decoder: the dense-output models (one
+# output per pixel / sample, nothing averaged behind the decoder) owe almost all of their error to operand rounding in
+# the decoder (tools/policy_mix.py, full-size flow: x2w everywhere 5.8e-4 / 1.5e-3; decoder alone at x3 1.1e-4 /
+# 1.1e-4; everything at x3 5e-6 at 9x the time), so they run the encoder on the fused single-sweep kernels and only the
+# decoder with split operands.
+DEFAULT_POLICY = {"ClassificationPerceiver": "fp16x2w", "LanguagePerceiver": "fp16x2w",
+                  "FlowPerceiver": "fp16x2w/fp16x3", "MultiModalPerceiver": "fp16x2w/fp16x3"}
+
+
+def split_policy(policy):
+    """"A/B" -> (A, B); a plain name (or None) applies to both halves."""
+    if policy is not None and "/" in policy:
+        enc, dec = policy.split("/", 1)
+        return enc, dec
+    return policy, policy
+
+
+class _policy_scope:
+    """Runs a block under a task model's precision policy: the ambient policy is the encoder's, the decoder's override
+    is set on the PerceiverIO core for the duration."""
+
+    def __init__(self, model):
+        self._model = model
+        enc, dec = split_policy(model.precision_policy)
+        self._ctx = precision(enc)
+        self._dec = dec if dec != enc else None
+
+    def __enter__(self):
+        self._saved = self._model.perceiver.decoder_policy
+        self._model.perceiver.decoder_policy = self._dec
+        self._ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        self._model.perceiver.decoder_policy = self._saved
+        return self._ctx.__exit__(*exc)
 
 
 class PrepType(Enum):
@@ -83,7 +117,7 @@ class ClassificationPerceiver(nn.Module):
 
     def forward(self, img: torch.Tensor):
         """img: (batch, channels, H, W) -> logits (batch, num_classes)."""
-        with precision(self.precision_policy):
+        with _policy_scope(self):
             return self.perceiver(img)
 
 
@@ -107,7 +141,7 @@ class LanguagePerceiver(nn.Module):
             output_queries=TrainableQuery(output_index_dims=max_seq_len, num_channels=embed_dim))
 
     def forward(self, inputs: torch.Tensor, input_masks: torch.Tensor):
-        with precision(self.precision_policy):
+        with _policy_scope(self):
             return self.perceiver(inputs, input_mask=input_masks, query_mask=input_masks)
 
 
@@ -159,7 +193,7 @@ class FlowPerceiver(nn.Module):
         return itertools.product(ys, xs)
 
     def _predict_patch(self, patch):
-        with precision(self.precision_policy):
+        with _policy_scope(self):
             return self.perceiver(patches_for_flow(patch).movedim(-1, -3), query_shard=self.query_shard)
 
     def forward(self, image1: torch.Tensor, image2: torch.Tensor, test_mode: bool = False, min_overlap: int = 20):
@@ -243,7 +277,7 @@ class MultiModalPerceiver(nn.Module):
             input_mask_probs={"image": 0.0, "audio": 0.0, "label": 1.0})
 
     def forward(self, images: torch.Tensor, audio: torch.Tensor, n_chunks: int = 128):
-        with precision(self.precision_policy):
+        with _policy_scope(self):
             return self._forward(images, audio, n_chunks)
 
     def _forward(self, images, audio, n_chunks):
@@ -267,7 +301,9 @@ class MultiModalPerceiver(nn.Module):
                 x, sizes, without_pos, latents = cached
                 query, qsizes = P.decoder_query(x, sizes, without_pos, subsampled_points=points)
                 from .perceiver import restructure
-                per_mod = restructure(qsizes, P._decoder(query, latents))
+                with precision(P.decoder_policy):
+                    dec_out = P._decoder(query, latents)
+                per_mod = restructure(qsizes, dec_out)
                 out = {m: post(per_mod[m], pos=None, modality_sizes=None)
                        for m, post in P._output_postprocessors.items()}
             rec["image"].append(out["image"])

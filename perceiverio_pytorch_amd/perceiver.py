@@ -330,6 +330,11 @@ class PerceiverIO(nn.Module):
         # postprocessors.py:180-187) gets the same values from the rows alone -- ClassificationPerceiver(
         # decode_row0_only=True) sets slice(0, 1) and skips 999 / 1000 of the decoder's work.
         self.decoder_query_rows = None
+        # Optional precision policies of the two halves (None = the ambient policy): dense-output models are far more
+        # sensitive to operand rounding in the DECODER (no averaging behind it) than in the encoder -- the full-size
+        # optical-flow model meets 1e-3 with "fp16x2w" everywhere except the decoder (tools/policy_mix.py).
+        self.encoder_policy = None
+        self.decoder_policy = None
 
     # Fused preprocessing hand-off (on by default): a single image modality whose network input is [conv features |
     # batch-invariant Fourier / learned position table] reaches the encoder as those two arrays
@@ -384,23 +389,26 @@ class PerceiverIO(nn.Module):
             latents0 = self._encoder.latents(feats)
             query, query_sizes = self.decoder_query(feats, sizes, without_pos,
                                                     subsampled_points=subsampled_output_points)
-            latents = self._encoder((feats, table), latents0, input_mask=input_mask)
+            with R.precision(self.encoder_policy):
+                latents = self._encoder((feats, table), latents0, input_mask=input_mask)
         else:
             x, sizes, without_pos = self._multi_preprocessor(inputs, pos=pos)
             latents0 = self._encoder.latents(x)
             query, query_sizes = self.decoder_query(x, sizes, without_pos, subsampled_points=subsampled_output_points)
-            latents = self._encoder(x, latents0, input_mask=input_mask)
+            with R.precision(self.encoder_policy):
+                latents = self._encoder(x, latents0, input_mask=input_mask)
         if self.decoder_query_rows is not None:
             query = query[:, self.decoder_query_rows]
             if query_mask is not None:
                 query_mask = query_mask[:, self.decoder_query_rows]
             assert len(query_sizes) == 1, "decoder_query_rows is defined for a single output modality"
             query_sizes = {m: query.shape[1] for m in query_sizes}
-        if query_shard is not None:
-            from .dist import decode_query_sharded
-            outputs = decode_query_sharded(self._decoder, query, latents, query_mask, *query_shard)
-        else:
-            outputs = self._decoder(query, latents, query_mask=query_mask)
+        with R.precision(self.decoder_policy):
+            if query_shard is not None:
+                from .dist import decode_query_sharded
+                outputs = decode_query_sharded(self._decoder, query, latents, query_mask, *query_shard)
+            else:
+                outputs = self._decoder(query, latents, query_mask=query_mask)
         if self._output_postprocessors:
             per_mod = restructure(query_sizes, outputs)
             outputs = {m: post(per_mod[m], pos=None, modality_sizes=None)

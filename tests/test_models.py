@@ -28,7 +28,8 @@ def test_default_policies_are_the_validated_ones():
     from perceiverio_pytorch_amd import models as M
     assert M.ClassificationPerceiver().precision_policy == "fp16x2w"
     assert M.DEFAULT_POLICY == {"ClassificationPerceiver": "fp16x2w", "LanguagePerceiver": "fp16x2w",
-                                "FlowPerceiver": "fp16x3", "MultiModalPerceiver": "fp16x3"}
+                                "FlowPerceiver": "fp16x2w/fp16x3", "MultiModalPerceiver": "fp16x2w/fp16x3"}
+    assert M.split_policy("fp16x2w/fp16x3") == ("fp16x2w", "fp16x3") and M.split_policy("fp16") == ("fp16", "fp16")
 
 
 @pytest.mark.parametrize("name", sorted(MODEL_CASES))
@@ -98,7 +99,7 @@ def test_benchmarked_path_matches_reference(name, policy):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("policy", ["fp16x3", "fp16x2w"])
+@pytest.mark.parametrize("policy", ["fp16x3", "fp16x2w/fp16x3", "fp16x2w"])
 def test_multimodal_full_size_chunks_match_reference(policy):
     """BASELINE config 5 at full size (M = 52 097 x 704 single-head cross-attend, 784 x 512 latents, 6 288-row decoder
     chunks): output chunks 0 and 127 of the reference's 128-chunk loop (multimodal_perceiver.py:146-157)."""
@@ -112,10 +113,14 @@ def test_multimodal_full_size_chunks_match_reference(policy):
     b, t, ch, h, w = images.shape
     ics = t * h * w // c["n_chunks"]
     acs = audio.shape[1] // model.audio_samples_per_patch // c["n_chunks"]
-    # parity claim: the class default (fp16x3) at 1e-4.  fp16x2w is a characterisation, as for the full-size flow model:
+    # parity claims: fp16x3 at 1e-4 and the class default ("fp16x2w/fp16x3": encoder on the fused single-sweep kernels,
+    # decoder with split operands) at 1e-3.  fp16x2w everywhere is a characterisation, as for the full-size flow model:
     # dense per-pixel outputs with no averaging behind the decoder sit at relL2 5e-4 but max-abs/abs-max 1.3e-3
-    tol = 2e-3 if policy != "fp16x3" else 1e-4
-    with torch.inference_mode(), precision(policy):
+    from perceiverio_pytorch_amd.models import split_policy
+    tol = {"fp16x3": 1e-4, "fp16x2w/fp16x3": TOL}.get(policy, 2e-3)
+    enc_pol, dec_pol = split_policy(policy)
+    model.perceiver.decoder_policy = dec_pol if dec_pol != enc_pol else None
+    with torch.inference_mode(), precision(enc_pol):
         for k in c["chunks"]:
             sub = {"image": torch.arange(ics * k, ics * (k + 1)), "audio": torch.arange(acs * k, acs * (k + 1)),
                    "label": None}
@@ -127,7 +132,7 @@ def test_multimodal_full_size_chunks_match_reference(policy):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("policy", ["fp16x3", "fp16x2w"])
+@pytest.mark.parametrize("policy", ["fp16x3", "fp16x2w", "fp16x2w/fp16x3"])
 @pytest.mark.parametrize("name", sorted(n for n in MODEL_CASES if n not in B4_CASES and n != "model_multimodal_full"))
 def test_model_outputs_match_reference(name, policy):
     import perceiverio_pytorch_amd as P
@@ -145,10 +150,10 @@ def test_model_outputs_match_reference(name, policy):
             # to the whole field's magnitude (stored with the golden).
             y = model(ins[0], ins[1])
             assert y.shape == (1, 2, 368, 496)
-            if policy != "fp16x3":
-                # characterisation, not a parity claim: with single-fp16 activations the dense per-pixel decoder
-                # (no averaging after it) reaches relL2 6e-4 but max/absmax 1.6e-3 on this model -> the 1e-3 bar
-                # is met by the default fp16x3 policy only; the bound below just pins the measured behaviour.
+            if policy == "fp16x2w":
+                # characterisation, not a parity claim: with single-fp16 activations in the DECODER the dense
+                # per-pixel output (no averaging after it) reaches relL2 6e-4 but max/absmax 1.5e-3 on this model;
+                # the class default "fp16x2w/fp16x3" (decoder with split operands) and fp16x3 are held to the bar.
                 tol = 2.5e-3
             _close(y[:, :, ::8, ::8], g["out_sub"], name, tol, absmax=g["out_absmax"])
         elif c["cls"] == "FlowPerceiver":

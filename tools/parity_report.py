@@ -47,7 +47,8 @@ def main():
                         acs = audio.shape[1] // model.audio_samples_per_patch // c["n_chunks"]
                         sub = {"image": torch.arange(ics * k, ics * (k + 1)),
                                "audio": torch.arange(acs * k, acs * (k + 1)), "label": None}
-                        with precision(policy):
+                        from perceiverio_pytorch_amd.models import _policy_scope
+                        with _policy_scope(model):
                             return model.perceiver({"image": images, "audio": audio,
                                                     "label": torch.zeros((b, model.num_classes), device=dev)},
                                                    subsampled_output_points=sub)
