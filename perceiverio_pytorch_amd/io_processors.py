@@ -337,6 +337,16 @@ class AudioPreprocessor(nn.Module, _PosMixin):
 # ---------------------------------------------------------------------------------------------------
 # postprocessors: forward(inputs, *, pos=None, modality_sizes=None)
 # ---------------------------------------------------------------------------------------------------
+def _linear(mod: nn.Linear, x: torch.Tensor, cache: dict) -> torch.Tensor:
+    """The nn.Linear heads right behind the decoder run through libpio_hip.so (runtime.hip_linear: pio_gemm_nt under
+    the current -- decoder -- precision policy) on the GPU; on CPU tensors the stock torch path (plumbing tests)."""
+    if x.is_cuda:
+        from .runtime import hip_linear
+        return hip_linear(x, mod.weight, mod.bias, cache)
+    return mod(x)
+
+
+
 class EmbeddingPostprocessor(nn.Module):
     """Logits against the (tied) token embedding + bias (postprocessors.py:12-34)."""
 
@@ -398,9 +408,10 @@ class AudioPostprocessor(nn.Module):
         self.linear = nn.Linear(in_channels, samples_per_patch)
         lecun_normal_(self.linear.weight)
         nn.init.constant_(self.linear.bias, 0)
+        self._pio_linear = {}
 
     def forward(self, inputs: torch.Tensor, *, pos=None, modality_sizes=None) -> torch.Tensor:
-        return self.linear(inputs).reshape(inputs.shape[0], -1)
+        return _linear(self.linear, inputs, self._pio_linear).reshape(inputs.shape[0], -1)
 
 
 class IdentityPostprocessor(nn.Module):
@@ -415,13 +426,16 @@ class ClassificationPostprocessor(nn.Module):
         super().__init__()
         self._num_classes = num_classes
         self._project = project
+        self._pio_linear = {}
         if project:
             self.linear = nn.Linear(num_input_channels, num_classes)
             lecun_normal_(self.linear.weight)
             nn.init.constant_(self.linear.bias, 0)
 
     def forward(self, inputs: torch.Tensor, *, pos=None, modality_sizes=None) -> torch.Tensor:
-        return (self.linear(inputs) if self._project else inputs)[:, 0, :]
+        # (rows are independent: the head is applied to the one row that is kept)
+        row0 = inputs[:, 0:1, :]
+        return (_linear(self.linear, row0, self._pio_linear) if self._project else row0)[:, 0, :]
 
 
 class ProjectionPostprocessor(nn.Module):
@@ -433,9 +447,10 @@ class ProjectionPostprocessor(nn.Module):
         self.projection = nn.Linear(num_inputs, num_outputs)
         lecun_normal_(self.projection.weight)
         nn.init.constant_(self.projection.bias, 0)
+        self._pio_linear = {}
 
     def forward(self, inputs: torch.Tensor, *, pos=None, modality_sizes=None) -> torch.Tensor:
-        return self.projection(inputs)
+        return _linear(self.projection, inputs, self._pio_linear)
 
 
 class FlowPostprocessor(nn.Module):

@@ -411,8 +411,9 @@ class PerceiverIO(nn.Module):
                 outputs = self._decoder(query, latents, query_mask=query_mask)
         if self._output_postprocessors:
             per_mod = restructure(query_sizes, outputs)
-            outputs = {m: post(per_mod[m], pos=None, modality_sizes=None)
-                       for m, post in self._output_postprocessors.items()}
+            with R.precision(self.decoder_policy):       # (the heads behind the decoder belong to its half)
+                outputs = {m: post(per_mod[m], pos=None, modality_sizes=None)
+                           for m, post in self._output_postprocessors.items()}
         if type(outputs) is not torch.Tensor and list(outputs.keys()) == ["__default"]:
             outputs = outputs["__default"]
         return outputs

@@ -160,13 +160,19 @@ def test_model_outputs_match_reference(name, policy):
             _close(model(ins[0][..., :48, :64], ins[1][..., :48, :64]), g["out_train"], name + " train", tol)
             _close(model(ins[0], ins[1], test_mode=True, min_overlap=10), g["out_test"], name + " tiled", tol)
         elif c["cls"] == "MultiModalPerceiver":
+            if policy == "fp16x2w":
+                tol = 2e-3     # characterisation (dense reconstruction, single-fp16 decoder + heads): see flow_full above
             out = model(ins[0], ins[1], n_chunks=2)
             _close(out["image"], g["out_image"], name + " image", tol)
             _close(out["audio"], g["out_audio"], name + " audio", tol)
             _close(out["label"], g["out_label"], name + " label", tol)
-            model.encode_once = False            # the reference's recompute-per-chunk loop gives the same result
+            model.decode_chunks_per_call = 1     # one decoder call per chunk ...
+            out1 = model(ins[0], ins[1], n_chunks=2)
+            model.encode_once = False            # ... and the reference's recompute-per-chunk loop give the same result
             out2 = model(ins[0], ins[1], n_chunks=2)
-            assert torch.equal(out2["image"], out["image"]) and torch.equal(out2["label"], out["label"])
+            assert torch.equal(out2["image"], out1["image"]) and torch.equal(out2["label"], out1["label"])
+            # several chunks per decoder call: the same rows through taller GEMMs (other tile shapes, same arithmetic)
+            _close(out["image"], out1["image"].cpu().numpy(), name + " chunk grouping", 1e-5 if policy == "fp16x3" else 5e-4)
         elif c["cls"] == "LanguagePerceiver":
             out = model(ins[0], ins[1])
             _close(out[:, :96], g["out"], name + " head", tol, absmax=g["out_absmax"])
