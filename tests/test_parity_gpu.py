@@ -857,6 +857,9 @@ XATTN_CASES = [
     (8, 32, 96, 2, 700, 256, "query", False),      # language decoder
     (4, 64, 64, 2, 100, 333, "key", False),        # generic narrow heads on the (128, 128) instantiation
     (2, 128, 128, 1, 77, 150, "query", False),
+    (1, 322, 322, 2, 1, 5, "key", False),          # edge: one query row, fewer keys than one 32-key tile
+    (8, 32, 96, 1, 3, 33, "query", False),         # edge: a second tile holding a single key
+    (1, 512, 512, 2, 129, 31, None, True),         # edge: ragged query tile, Tk = tile - 1, broadcast Q
 ]
 
 
