@@ -285,6 +285,14 @@ int gemm_nt_launch(const pio_gemm_t &g, hipStream_t s) {
     p.ln_part = g.ln_part; p.ln_c = g.ln_c; p.ln_eps = g.ln_eps;
     p.X16_lo = g.X16_lo; p.R16_hi = g.R16_hi; p.R16_lo = g.R16_lo;
     p.lo_n0 = g.B_lo ? g.b_lo_n0 : 0;
+    {
+        // A/B switch: env PIO_WIDE_STAGED_EPI=0 keeps the direct (16 rows x 64 bytes per instruction) epilogue
+        static const int staged = [] {
+            const char *e = getenv("PIO_WIDE_STAGED_EPI");
+            return (e && atoi(e) == 0) ? 0 : 1;
+        }();
+        p.staged_epi = staged;
+    }
     if (g.b_lo_n0 && (!g.B_lo || g.A_lo)) return PIO_E_ARG;
     p.n_store = g.n_store > g.N ? g.n_store : g.N;
     if (g.C && p.n_store > g.ldc) return PIO_E_SHAPE;

@@ -8,6 +8,7 @@ struct GemmParams {
     const void *A, *B;
     int64_t dA1, dB1, dA2, dB2;  // element offsets of the pass-1 / pass-2 operands relative to A / B
     int npass;                   // 1..3 K sweeps accumulating into the same registers
+    int staged_epi;              // (gemm_nt_wide, LayerNorm-fold producer) 1: LDS-staged, row-coalesced epilogue
     int lo_n0;                   // (gemm_nt_wide only) B_lo exists for columns >= lo_n0 (multiple of 256); 0 = all
     void *C, *C_lo;
     int M, N, K;

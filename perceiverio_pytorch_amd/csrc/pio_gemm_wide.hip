@@ -398,6 +398,94 @@ __global__ __launch_bounds__(256) void gemm_nt_wide(const GemmParams p, int tile
 #endif
         const int t_m0 = o_m - (wm * 128 + fr), t_n0 = o_n0 - wn * 128;  // the tile's origin (wave-uniform)
         const bool interior = t_m0 + W_BM <= p.M && t_n0 + W_BN <= p.N;
+        if constexpr (LNF == 1 && RES == 2) {
+            // ---- LDS-STAGED epilogue of the LayerNorm fold's producer (the last tile of this workgroup, i.e. every
+            // tile of the one-tile-per-CU out / fc2 projections): the ring is free now, so the accumulators of a row
+            // block go through this wave's 32 KiB of it and come back in a ROW-COALESCED arrangement -- lane -> (row
+            // lane >> 4, eight consecutive columns (lane & 15) * 8).  Every residual load and every store then covers
+            // 4 rows x 256 contiguous bytes (whole 128-byte lines) instead of 16 rows x 64 bytes (half lines, each line
+            // written by two instructions): the direct epilogue below moves its 128 MB per launch at 4.4 TB/s.
+            if (!p.C && p.X16_lo && p.staged_epi && interior && j == ntl - 1) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();  // every wave has read its last fragments out of the ring
+                constexpr int ROWP = 132;      // floats per staged row: 128 + 4 (conflict-free b128 writes and reads)
+                float *const stg = (float *)(smem + wave * 32768);
+                const int cr = lane >> 4, cc = (lane & 15) * 8;
+                const f32x4 bc0 = *(const f32x4 *)(bstash + cc), bc1 = *(const f32x4 *)(bstash + cc + 4);
+                const int m_w = o_m - fr;      // first row of this wave's quarter
+                const int n_c = o_n0 + cc;     // this lane's first column in the coalesced arrangement
+                const T *const r_hi = (const T *)p.R16_hi + (int64_t)(m_w + cr) * p.ld16 + n_c;
+                const T *const r_lo = (const T *)p.R16_lo + (int64_t)(m_w + cr) * p.ld16 + n_c;
+                T *const x_hi = (T *)p.X16 + (int64_t)(m_w + cr) * p.ld16 + n_c;
+                T *const x_lo = (T *)p.X16_lo + (int64_t)(m_w + cr) * p.ld16 + n_c;
+                float *const part = p.row_part + ((int64_t)(m_w + cr) * (p.N >> 7) + (o_n0 >> 7)) * 2;
+                const int64_t rstep4 = 4 * p.ld16;          // elements per 4 rows
+                V8 rh[2][4], rl[2][4];
+                auto r_load = [&](int set, int mi) {
+#pragma unroll
+                    for (int st = 0; st < 4; ++st) {
+                        rh[set][st] = *(const V8 *)(r_hi + (int64_t)(mi * 4 + st) * rstep4);
+                        rl[set][st] = *(const V8 *)(r_lo + (int64_t)(mi * 4 + st) * rstep4);
+                    }
+                };
+                r_load(0, 0);
+#pragma unroll
+                for (int mi = 0; mi < 8; ++mi) {
+                    if (mi < 7) r_load((mi + 1) & 1, mi + 1);
+                    // accumulators of row block mi -> LDS, accumulator arrangement (row fr, 8 columns at 32 pp + 8 fq)
+#pragma unroll
+                    for (int pp = 0; pp < 4; ++pp) {
+                        f32x4 x0, x1;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            x0[r] = acc_read(acc[mi][2 * pp][r]);
+                            x1[r] = acc_read(acc[mi][2 * pp + 1][r]);
+                        }
+                        *(f32x4 *)(stg + fr * ROWP + 32 * pp + 8 * fq) = x0;
+                        *(f32x4 *)(stg + fr * ROWP + 32 * pp + 8 * fq + 4) = x1;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    // ... and back, row-coalesced: 4 steps of 4 rows (LDS operations of one wave execute in order)
+#pragma unroll
+                    for (int st = 0; st < 4; ++st) {
+                        const f32x4 a0 = *(const f32x4 *)(stg + (st * 4 + cr) * ROWP + cc);
+                        const f32x4 a1 = *(const f32x4 *)(stg + (st * 4 + cr) * ROWP + cc + 4);
+                        const V8 hh = rh[mi & 1][st], ll = rl[mi & 1][st];
+                        f32x4 x0, x1;
+                        float rsum = 0.f, rsq = 0.f;
+                        V8 h, l;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            x0[r] = a0[r] * p.alpha + bc0[r] + (Op<DT>::to_f32(hh[r]) + Op<DT>::to_f32(ll[r]));
+                            x1[r] = a1[r] * p.alpha + bc1[r] + (Op<DT>::to_f32(hh[4 + r]) + Op<DT>::to_f32(ll[4 + r]));
+                            rsum += x0[r] + x1[r];
+                            rsq += x0[r] * x0[r] + x1[r] * x1[r];
+                            h[r] = Op<DT>::from_f32(x0[r]);
+                            h[4 + r] = Op<DT>::from_f32(x1[r]);
+                            l[r] = Op<DT>::from_f32(x0[r] - Op<DT>::to_f32(h[r]));
+                            l[4 + r] = Op<DT>::from_f32(x1[r] - Op<DT>::to_f32(h[4 + r]));
+                        }
+                        const int64_t ro = (int64_t)(mi * 4 + st) * rstep4;
+                        *(V8 *)(x_hi + ro) = h;
+                        *(V8 *)(x_lo + ro) = l;
+                        // the 16 lanes of a row hold 8 columns each: four butterfly steps, lane (lane & 15) == 0 writes
+                        // the row's (sum, sum of squares) over this wave's 128-column block
+#pragma unroll
+                        for (int sh = 1; sh < 16; sh <<= 1) {
+                            rsum += __shfl_xor(rsum, sh);
+                            rsq += __shfl_xor(rsq, sh);
+                        }
+                        if ((lane & 15) == 0) {
+                            float *dstp = part + (int64_t)(mi * 16 + st * 4) * (p.N >> 7) * 2;
+                            dstp[0] = rsum;
+                            dstp[1] = rsq;
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                continue;
+            }
+        }
         if constexpr (OUT == 2) {
             // fp32 out [+ residual]: 64 stores of 4 columns; the residual of row block mi+1 is loaded while block mi
             // is converted and stored
