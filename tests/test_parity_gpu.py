@@ -1031,3 +1031,44 @@ def test_layernorm_cast_cat_equals_layernorm_of_concatenation(dev):
                        gamma.astype(np.float64), beta.astype(np.float64))
     got = (ya.float() + la.float()).cpu().numpy().reshape(B, T, cp)
     assert np.abs(got[..., :C1 + C2] - ref).max() <= 2e-6 and (got[..., C1 + C2:] == 0).all()
+
+
+def test_fused_cross_attention_fuzz(dev):
+    """Seeded random shapes / masks through the fused cross-attention kernel against the materialised path of the same
+    policy (full mask tensor): every instantiation, ragged tiles, key splits, dv slices, broadcast Q."""
+    from perceiverio_pytorch_amd.transformer_primitives import Attention
+    rng = np.random.default_rng(2024)
+    widths = [(1, 322, 322), (1, 264, 264), (1, 512, 512), (1, 704, 704), (1, 400, 320), (8, 32, 160), (8, 32, 96),
+              (4, 64, 64), (2, 128, 128), (3, 40, 24), (1, 136, 200)]
+    _policy("fp16")
+    for it in range(22):
+        H, dk, dv = widths[it % len(widths)]
+        B = int(rng.integers(1, 4))
+        Tq = int(rng.integers(1, 600))
+        Tk = int(rng.integers(1, 3000))
+        mk = [None, "key", "query"][int(rng.integers(0, 3))]
+        bcast = bool(rng.integers(0, 2))
+        q_in, kv_in = 64, 96
+        p = O.gen_attention("", q_in, kv_in, H * dk, H * dv, q_in, seed=100 + it)
+        xq = rng.standard_normal((1 if bcast else B, Tq, q_in)).astype(np.float32)
+        xkv = rng.standard_normal((B, Tk, kv_in)).astype(np.float32)
+        qm = km = None
+        if mk == "key":
+            km = rng.random((B, Tk)) > 0.4
+            if B > 1:
+                km[B - 1, :] = False                 # one sample without any attendable key
+        elif mk == "query":
+            qm = rng.random((B, Tq)) > 0.4
+        m = Attention(q_in, kv_in, kv_in, num_heads=H, qk_out_channels=H * dk, v_out_channels=H * dv,
+                      output_channels=q_in)
+        m.load_state_dict(_sd(p, "cpu"))
+        m = m.to(dev).eval()
+        xq_t = _t(xq, dev)
+        if bcast:
+            xq_t = torch.broadcast_to(xq_t, (B, Tq, q_in))
+        y = _attention_vector_masks(m, xq_t, _t(xkv, dev), km, qm, dev)
+        mask3 = O.make_cross_attention_mask(qm if qm is not None else np.ones((B, Tq), bool),
+                                            km if km is not None else np.ones((B, Tk), bool))
+        ym = m(xq_t, _t(xkv, dev), _t(xkv, dev), attention_mask=_t(mask3, dev))
+        assert torch.isfinite(y).all(), (it, H, dk, dv, B, Tq, Tk, mk)
+        _assert_close(y, ym.detach().cpu().numpy(), TOL, what=f"fuzz {it}: H={H} dk={dk} dv={dv} B={B} Tq={Tq} Tk={Tk} {mk}")
