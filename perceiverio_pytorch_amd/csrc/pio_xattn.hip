@@ -303,6 +303,7 @@ __global__ __launch_bounds__(256, (DKL <= 128 && DVS <= 160) ? 2 : 1) void xattn
         for (int i = 0; i < RV; ++i) vf[i] = v_read(i);
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (PIN) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // MFMA write of S^T -> VALU reads
+        __builtin_amdgcn_sched_barrier(0);  // (nothing that reads S^T may be scheduled in front of the padding)
 
         // ---- key mask / tail: accumulator register i is key k0 + 16 (i >> 3) + 8 hh + (i & 7); one 32-bit word per
         // tile (a SCALAR load: uniform address), bit j = key k0 + j is attendable
@@ -361,6 +362,7 @@ __global__ __launch_bounds__(256, (DKL <= 128 && DVS <= 160) ? 2 : 1) void xattn
                 if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
             }
             if constexpr (PIN) asm volatile("s_nop 7" ::: "memory");  // VALU write of O^T -> MFMA reads it as SrcC
+            __builtin_amdgcn_sched_barrier(0);
         }
         // ---- P^T fragments: registers 8 s .. 8 s + 7 are keys 16 s + 8 hh + 0..7 = the B operand of k-step s
         V8 pf[2];
@@ -371,6 +373,7 @@ __global__ __launch_bounds__(256, (DKL <= 128 && DVS <= 160) ? 2 : 1) void xattn
         // ---- O^T += V^T P^T: the A fragment of (d tile, k-step s2) is ONE 16-byte chunk of V^T row 32 d + r32
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (PIN) asm volatile("s_nop 3" ::: "memory");  // VALU write of P^T -> MFMA reads it as SrcB
+        __builtin_amdgcn_sched_barrier(0);
         xa_for<0, NVF>([&](auto FI) {
             constexpr int f = decltype(FI)::value;
             constexpr int d = f >> 1, s2 = f & 1;
@@ -380,7 +383,9 @@ __global__ __launch_bounds__(256, (DKL <= 128 && DVS <= 160) ? 2 : 1) void xattn
             __builtin_amdgcn_sched_barrier(0);
         });
     }
+    __builtin_amdgcn_sched_barrier(0);
     if constexpr (PIN) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // last MFMA write of O^T -> VALU reads
+    __builtin_amdgcn_sched_barrier(0);
 
     // ---- epilogue
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
