@@ -82,7 +82,10 @@ typedef struct pio_attention_t {
     int32_t dkp, dvp; /* padded (multiple of 8)                    */
     int32_t q_in, k_in, v_in, out; /* logical channel counts (k_in == v_in inside Self/CrossAttention) */
     int32_t dtype;     /* PIO_DT_*                                  */
-    int32_t act_split; /* 1: activations are carried as hi+lo pairs too (3 MFMA sweeps, ~fp32 products) */
+    int32_t act_split; /* 1: activations are carried as hi+lo pairs too (3 MFMA sweeps, ~fp32 products);
+                          2: the same for the four projections, but the attention core (Q K^T, softmax, P V) runs
+                          single-sweep on the hi halves through the fused kernel wherever one covers the shape (no
+                          score matrix) and returns its output as a pair                                      */
     pio_linear_t qk;   /* optional (w_hi may be NULL): proj_q and proj_k stacked along the output rows
                           [q rows | k rows], used as ONE GEMM when inputs_q and inputs_k are the same tensor */
     pio_linear_t qkv;  /* optional (w_hi may be NULL): [q rows | k rows | v rows] for self-attention with

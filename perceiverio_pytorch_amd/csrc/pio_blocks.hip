@@ -157,6 +157,7 @@ static ScoreChunks score_chunks(int B, int H, int Tq, int Tk) {
 // true when attention_core will take a fused (score-free) kernel for every call that passes no full mask / bias /
 // probability output: the plans of the encoder / decoder (which never pass those) then carve no score buffers at all
 static bool fused_capable(const pio_attention_t &a) {
+    if (a.act_split == 2) return xattn_supported(a.dkp, a.dvp);  // split projections, single-sweep fused core
     return !a.act_split && (flash_supported(a.dkp, a.dvp) || xattn_supported(a.dkp, a.dvp));
 }
 
@@ -183,7 +184,8 @@ struct AttnScratch {
             p16 = take_pair(c, (size_t)ch.b_chunk * a.heads * ch.q_chunk * tkp, sp);
         }
         o16 = take_pair(c, (size_t)B * Tq * ldo, sp);
-        const size_t xb = (!sp && xattn_supported(a.dkp, a.dvp)) ? xattn_partial_bytes(a.dkp, a.dvp, B, a.heads, Tq, Tk) : 0;
+        const size_t xb = (a.act_split != 1 && xattn_supported(a.dkp, a.dvp))
+                              ? xattn_partial_bytes(a.dkp, a.dvp, B, a.heads, Tq, Tk) : 0;
         xpart = xb ? c.take(xb) : nullptr;
     }
 };
@@ -281,15 +283,19 @@ static int attention_core(const pio_attention_t &a, Pair xq, bool q_bcast, Pair 
     //      single-sweep: the self-attention kernel (pio_flash.hip) for un-masked attention with its head widths, the
     //      cross-attention kernel (pio_xattn.hip) for key / query mask VECTORS, wide single heads, dv != dk and few
     //      query tiles (key splits).  Otherwise the materialised path below.
-    const bool score_free = !a.act_split && !full_mask && !attention_bias && !probs_out;
-    if (score_free && !kv_mask && !q_mask && flash_supported(a.dkp, a.dvp)) {
+    // act_split == 2 ("x3f"): the projections around the core run with split operands, the core itself single-sweep
+    // on the hi halves of q / k / v^T through the fused cross-attention kernel, which returns its output as a pair.
+    const bool single_core = a.act_split == 2;
+    const bool score_free = (!a.act_split || single_core) && !full_mask && !attention_bias && !probs_out;
+    if (score_free && !single_core && !kv_mask && !q_mask && flash_supported(a.dkp, a.dvp)) {
         PIO_TRY(flash_attention_launch(a.dtype, a.dkp, a.dvp, a.dk, w.q16.hi, k_hi, w.vt16.hi, w.o16.hi, B, H, Tq,
                                        Tk, ldq, ldq, tkv, ldo, q_bcast ? 0 : (int64_t)Tq * ldq, (int64_t)Tk * ldq,
                                        ldo * tkv, (int64_t)Tq * ldo, false, s));
         return linear_fwd(a.o, a.dtype, w.o16, (int64_t)B * Tq, out, nullptr, true, a.out, a.out, 0, res, s);
     }
     if (score_free && xattn_supported(a.dkp, a.dvp)) {
-        PIO_TRY(xattn_launch(a.dtype, a.dkp, a.dvp, a.dk, w.q16.hi, k_hi, w.vt16.hi, w.o16.hi, B, H, Tq, Tk, ldq, ldq,
+        PIO_TRY(xattn_launch(a.dtype, a.dkp, a.dvp, a.dk, w.q16.hi, k_hi, w.vt16.hi, w.o16.hi,
+                             single_core ? w.o16.lo : nullptr, B, H, Tq, Tk, ldq, ldq,
                              tkv, ldo, q_bcast ? 0 : (int64_t)Tq * ldq, (int64_t)Tk * ldq, ldo * tkv, (int64_t)Tq * ldo,
                              kv_mask, q_mask, w.xpart, s));
         return linear_fwd(a.o, a.dtype, w.o16, (int64_t)B * Tq, out, nullptr, true, a.out, a.out, 0, res, s);

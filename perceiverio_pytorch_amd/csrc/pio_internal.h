@@ -114,7 +114,7 @@ int flash_attention_launch(int dtype, int dkp, int dvp, int dk_logical, const vo
 bool xattn_supported(int dkp, int dvp);
 size_t xattn_partial_bytes(int dkp, int dvp, int B, int H, int Tq, int Tk);  // fp32 partials of the key splits (0: none)
 int xattn_launch(int dtype, int dkp, int dvp, int dk_logical, const void *Q, const void *K, const void *VT, void *O,
-                 int B, int H, int Tq, int Tk, int64_t ldq, int64_t ldk, int64_t ldvt, int64_t ldo, int64_t sQb,
+                 void *O_lo, int B, int H, int Tq, int Tk, int64_t ldq, int64_t ldk, int64_t ldvt, int64_t ldo, int64_t sQb,
                  int64_t sKb, int64_t sVb, int64_t sOb, const uint8_t *kv_mask, const uint8_t *q_mask, void *partials,
                  hipStream_t s);
 int pack_linear_launch(const float *w, const float *bias, int out, int in, int64_t ldw, int row_heads,

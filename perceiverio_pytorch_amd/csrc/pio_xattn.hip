@@ -45,6 +45,7 @@ __device__ __forceinline__ void xa_for(F &&f) {  // compile-time loop: the index
 struct XattnParams {
     const void *Q, *K, *VT;
     void *O;
+    void *O_lo;      // optional: the rounding residual o - float(O) (the output as a 16-bit pair)
     float *part_o;   // key split: [B*H][nsplit][Tq][dvp] un-normalised O
     float *part_ml;  // key split: [B*H][nsplit][Tq][2]   (running max in exp2 units, row sum)
     const uint8_t *q_mask;
@@ -416,17 +417,24 @@ __global__ __launch_bounds__(256, (DKL <= 128 && DVS <= 160) ? 2 : 1) void xattn
     bool live = l_tot > 0.f;  // no attendable key at all: the reference wipes the row to zeros
     if (p.q_mask) live = live && p.q_mask[(int64_t)b * p.Tq + q] != 0;
     const float inv = live ? 1.0f / l_tot : 0.f;
-    T *orow = (T *)p.O + b * p.sOb + (int64_t)q * p.ldo + (int64_t)h * p.dvp + d0;
+    const int64_t ooff = b * p.sOb + (int64_t)q * p.ldo + (int64_t)h * p.dvp + d0;
+    T *orow = (T *)p.O + ooff;
+    T *lrow = p.O_lo ? (T *)p.O_lo + ooff : nullptr;
 #pragma unroll
     for (int d = 0; d < NDT; ++d)
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
             const int col = 32 * d + 8 * g4 + 4 * hh;
             if (d0 + col < p.dvp) {
-                V4 o;
+                V4 o, l;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = Op<DT>::from_f32(oacc[d][4 * g4 + j] * inv);
+                for (int j = 0; j < 4; ++j) {
+                    const float v = oacc[d][4 * g4 + j] * inv;
+                    o[j] = Op<DT>::from_f32(v);
+                    l[j] = Op<DT>::from_f32(v - Op<DT>::to_f32(o[j]));
+                }
                 *(V4 *)(orow + col) = o;
+                if (lrow) *(V4 *)(lrow + col) = l;
             }
         }
 }
@@ -448,7 +456,7 @@ __global__ __launch_bounds__(256) void xattn_keybits_kernel(const uint8_t *kv_ma
 
 // Combines the key splits of one (batch, head, query row): O = sum_s O_s 2^(m_s - M) / sum_s l_s 2^(m_s - M).
 template <int DT>
-__global__ __launch_bounds__(256) void xattn_reduce_kernel(const float *part_o, const float *part_ml, void *O,
+__global__ __launch_bounds__(256) void xattn_reduce_kernel(const float *part_o, const float *part_ml, void *O, void *O_lo,
                                                            const uint8_t *q_mask, int H, int nsplit, int Tq, int dvp,
                                                            int64_t ldo, int64_t sOb, int64_t total) {
     typedef typename Op<DT>::T T;
@@ -479,10 +487,16 @@ __global__ __launch_bounds__(256) void xattn_reduce_kernel(const float *part_o, 
     bool live = L > 0.f;
     if (q_mask) live = live && q_mask[(int64_t)b * Tq + q] != 0;
     const float inv = live ? 1.0f / L : 0.f;
-    V4 o;
+    V4 o, l;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) o[j] = Op<DT>::from_f32(acc[j] * inv);
-    *(V4 *)((T *)O + b * sOb + (int64_t)q * ldo + (int64_t)h * dvp + c) = o;
+    for (int j = 0; j < 4; ++j) {
+        const float v = acc[j] * inv;
+        o[j] = Op<DT>::from_f32(v);
+        l[j] = Op<DT>::from_f32(v - Op<DT>::to_f32(o[j]));
+    }
+    const int64_t off = b * sOb + (int64_t)q * ldo + (int64_t)h * dvp + c;
+    *(V4 *)((T *)O + off) = o;
+    if (O_lo) *(V4 *)((T *)O_lo + off) = l;
 }
 
 // ---- host side -------------------------------------------------------------------------------------------------
@@ -530,7 +544,7 @@ size_t xattn_partial_bytes(int dkp, int dvp, int B, int H, int Tq, int Tk) {
 }
 
 int xattn_launch(int dtype, int dkp, int dvp, int dk_logical, const void *Q, const void *K, const void *VT, void *O,
-                 int B, int H, int Tq, int Tk, int64_t ldq, int64_t ldk, int64_t ldvt, int64_t ldo, int64_t sQb,
+                 void *O_lo, int B, int H, int Tq, int Tk, int64_t ldq, int64_t ldk, int64_t ldvt, int64_t ldo, int64_t sQb,
                  int64_t sKb, int64_t sVb, int64_t sOb, const uint8_t *kv_mask, const uint8_t *q_mask, void *partials,
                  hipStream_t s) {
     const XCfg *c = xattn_cfg(dkp, dvp);
@@ -539,7 +553,8 @@ int xattn_launch(int dtype, int dkp, int dvp, int dk_logical, const void *Q, con
     if (B <= 0 || H <= 0 || Tq <= 0 || Tk <= 0 || (dkp & 7) || (dvp & 7)) return PIO_E_SHAPE;
     if ((ldq % 8) || (ldk % 8) || (ldvt % 8) || (ldo % 4) || (sQb % 8) || (sKb % 8) || (sVb % 8) || (sOb % 4))
         return PIO_E_ALIGN;
-    if (((uintptr_t)Q & 15) || ((uintptr_t)K & 15) || ((uintptr_t)VT & 15) || ((uintptr_t)O & 7)) return PIO_E_ALIGN;
+    if (((uintptr_t)Q & 15) || ((uintptr_t)K & 15) || ((uintptr_t)VT & 15) || ((uintptr_t)O & 7) || ((uintptr_t)O_lo & 7))
+        return PIO_E_ALIGN;
     if (ldvt < 8 || 32 * ldk >= (1ll << 31) || (int64_t)dvp * ldvt >= (1ll << 31)) return PIO_E_SHAPE;
     const int nslice = (dvp + c->dvs - 1) / c->dvs;
     const int nqt = (Tq + 127) / 128;
@@ -551,7 +566,7 @@ int xattn_launch(int dtype, int dkp, int dvp, int dk_logical, const void *Q, con
     const int64_t nwg = (int64_t)B * H * nqt * nslice * nsplit;
     if (nwg > 0x7fffffffLL) return PIO_E_SHAPE;
     XattnParams p{};
-    p.Q = Q; p.K = K; p.VT = VT; p.O = O;
+    p.Q = Q; p.K = K; p.VT = VT; p.O = O; p.O_lo = O_lo;
     p.key_bits = kv_mask ? (const uint32_t *)partials : nullptr;
     p.part_o = (float *)((char *)partials + keybits_bytes(B, Tk));
     p.part_ml = nsplit > 1 ? p.part_o + (size_t)B * H * nsplit * Tq * dvp : nullptr;
@@ -586,10 +601,10 @@ int xattn_launch(int dtype, int dkp, int dvp, int dk_logical, const void *Q, con
             const int64_t total = (int64_t)B * H * Tq * (dvp / 4);
             dim3 rgrid((unsigned)((total + 255) / 256), 1, 1);
             if (dtype == PIO_DT_F16)
-                hipLaunchKernelGGL((xattn_reduce_kernel<PIO_DT_F16>), rgrid, block, 0, s, p.part_o, p.part_ml, O, q_mask,
-                                   H, nsplit, Tq, dvp, ldo, sOb, total);
+                hipLaunchKernelGGL((xattn_reduce_kernel<PIO_DT_F16>), rgrid, block, 0, s, p.part_o, p.part_ml, O, O_lo,
+                                   q_mask, H, nsplit, Tq, dvp, ldo, sOb, total);
             else
-                hipLaunchKernelGGL((xattn_reduce_kernel<PIO_DT_BF16>), rgrid, block, 0, s, p.part_o, p.part_ml, O,
+                hipLaunchKernelGGL((xattn_reduce_kernel<PIO_DT_BF16>), rgrid, block, 0, s, p.part_o, p.part_ml, O, O_lo,
                                    q_mask, H, nsplit, Tq, dvp, ldo, sOb, total);
         }
     }

@@ -29,8 +29,12 @@ from .position_encoding import PosEncodingType
 # the decoder (tools/policy_mix.py, full-size flow: x2w everywhere 5.8e-4 / 1.5e-3; decoder alone at x3 1.1e-4 /
 # 1.1e-4; everything at x3 5e-6 at 9x the time), so they run the encoder on the fused single-sweep kernels and only the
 # decoder with split operands.
+# The decoder half runs "x3f": split operands in every projection / MLP / head GEMM, the attention core itself
+# single-sweep on the fused kernel with its output returned as a pair (flow: 9.5e-5 / 2.0e-4 at 9.2 ms against 9.3e-5 /
+# 1.0e-4 at 12.0 ms with a fully 3-sweep decoder, and no score matrix at all: peak memory 0.7 instead of 4.6 GiB on
+# the full-size multimodal model).
 DEFAULT_POLICY = {"ClassificationPerceiver": "fp16x2w", "LanguagePerceiver": "fp16x2w",
-                  "FlowPerceiver": "fp16x2w/fp16x3", "MultiModalPerceiver": "fp16x2w/fp16x3"}
+                  "FlowPerceiver": "fp16x2w/fp16x3f", "MultiModalPerceiver": "fp16x2w/fp16x3f"}
 
 
 def split_policy(policy):

@@ -28,7 +28,11 @@ from . import _lib as L
 _POLICIES = {"fp16": (L.PIO_DT_F16, 0, False), "fp16x2s": (L.PIO_DT_F16, 1, False),
              "fp16x2w": (L.PIO_DT_F16, 2, False), "fp16x3": (L.PIO_DT_F16, 3, True),
              "bf16": (L.PIO_DT_BF16, 0, False), "bf16x2w": (L.PIO_DT_BF16, 2, False),
-             "bf16x3": (L.PIO_DT_BF16, 3, True)}
+             "bf16x3": (L.PIO_DT_BF16, 3, True),
+             # x3f: every GEMM with split operands as x3, but the attention core (Q K^T, softmax, P V) single-sweep on
+             # the fused kernels (q / k / v / p rounded once; the core's output leaves as a pair): no score matrix
+             "fp16x3f": (L.PIO_DT_F16, 3, True), "bf16x3f": (L.PIO_DT_BF16, 3, True)}
+_FUSED_CORE = {"fp16x3f", "bf16x3f"}
 _policy = os.environ.get("PIO_PRECISION", "fp16x3")
 if _policy not in _POLICIES:
     raise ValueError(f"PIO_PRECISION={_policy!r} not in {sorted(_POLICIES)}")
@@ -91,6 +95,11 @@ def range_check() -> bool:
 def set_range_check(on: bool) -> None:
     global _range_check
     _range_check = bool(on)
+
+
+def policy_core_single(name: Optional[str] = None) -> bool:
+    """True for the "x3f" policies: split operands in the projections, single-sweep fused attention core."""
+    return (name or _policy) in _FUSED_CORE
 
 
 def pad8(c: int) -> int:

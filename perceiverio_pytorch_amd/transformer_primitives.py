@@ -138,7 +138,7 @@ class Attention(_HipModule):
         dk, dv = self._qk_channels_per_head, self._v_channels_per_head
         d = L.Attention(q.desc, k.desc, v.desc, o.desc, H, dk, dv, R.pad8(dk), R.pad8(dv),
                         self.proj_q.in_features, self.proj_k.in_features, self.proj_v.in_features,
-                        self.final.out_features, dtype, int(split))
+                        self.final.out_features, dtype, (2 if R.policy_core_single() else 1) if split else 0)
         keep = [q, k, v, o]
         if self.proj_q.in_features == self.proj_k.in_features and not split:
             qk = R.PackedStack([(self.proj_q.weight, self.proj_q.bias), (self.proj_k.weight, self.proj_k.bias)],

@@ -889,7 +889,7 @@ def _attention_vector_masks(m, xq, xkv, kv_mask, q_mask, dev):
     return out
 
 
-@pytest.mark.parametrize("policy", ["fp16", "fp16x2w", "bf16"])
+@pytest.mark.parametrize("policy", ["fp16", "fp16x2w", "bf16", "fp16x3f"])
 @pytest.mark.parametrize("case", XATTN_CASES)
 def test_fused_cross_attention_vs_oracle(dev, case, policy):
     """Attention on the fused cross-attention kernel (mask vectors, wide heads, dv != dk, key splits) against the float64
@@ -927,7 +927,13 @@ def test_fused_cross_attention_vs_oracle(dev, case, policy):
     # (random toy weights on 64 / 96 input channels: operand rounding alone is ~1e-3 here -- the budget of the toy
     #  goldens; the kernel itself is held to TOL against the materialised path of the same policy below)
     tol = TOL if policy != "bf16" else 1e-2
-    _assert_close(y, ref, FAST_TOY_BUDGET if policy != "bf16" else 2e-2, what=f"fused cross-attention {case} {policy}")
+    if policy == "fp16x3f":
+        # split projections around a single-sweep fused core: only q / k / v / p are rounded once -- held to the 1e-3 bar
+        # against the oracle even on these toy widths (worst 3.8e-4 / 6.3e-4), and against the fully 3-sweep
+        # materialised path below
+        _assert_close(y, ref, TOL, what=f"fused cross-attention {case} {policy}")
+    else:
+        _assert_close(y, ref, FAST_TOY_BUDGET if policy != "bf16" else 2e-2, what=f"fused cross-attention {case} {policy}")
     if mk == "key_allfalse_b1":
         fb = m.final.bias.detach()
         assert torch.equal(y[1], fb[None, :].expand_as(y[1])), "sample without an attendable key must give final.bias"
