@@ -163,7 +163,8 @@ int pio_prof_end(double *ms, double *flops, double *bytes, int64_t *launches);
 int pio_ln_fold_enable(int on);
 
 /* --- kernel selection of pio_gemm_nt, for tests and A/B benchmarks ------------------------------- */
-/* 0: automatic (default; env PIO_GEMM_TILE gives the initial value), 128: 128x128 tile, 256: 256x256 tile,
+/* 0: automatic (default; env PIO_GEMM_TILE gives the initial value), 64: 64x64 tiles of the 128-tile kernel (automatic
+ * for problems with fewer than 192 tiles of 128x128: small batches), 128: 128x128 tile, 256: 256x256 tile,
  * 1: persistent 256x128 streaming kernel wherever it is legal, 2: persistent 256x256 four-wave kernel wherever
  * it is legal, 3: the LayerNorm-fold producer on the two-workgroups-per-CU kernel (gemm_nt_duo).  Returns the
  * previous setting. */

@@ -20,16 +20,22 @@ namespace pio {
 
 __device__ __attribute__((aligned(16))) uint32_t g_zero_chunk[4] = {0, 0, 0, 0};
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand tile
+constexpr int BM = 128, BN = 128, BK = 64;   // the default tile (launcher arithmetic); the kernel is templated on TM x TN
 
 // KIND only tags the instantiation (0: one flat [rows,K]x[N,K] linear, 1: batched attention product) so that
 // profilers report the two uses under different kernel names.
-template <int DT, int KIND>
+// TM x TN: 128 x 128 (four waves of 64 x 64) or 64 x 64 (four waves of 32 x 32: problems whose 128 x 128 tiling would
+// leave most of the 256 CUs idle -- a 2048-row latent stack at batch 1 has 64 such tiles per GEMM).
+template <int DT, int KIND, int TM, int TN>
 __global__ __launch_bounds__(256) void gemm_nt_128(const GemmParams p) {
     typedef typename Op<DT>::T T;
     typedef typename Op<DT>::V8 V8;
-    __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];  // A0 A1 B0 B1
+    constexpr int A_BYTES = TM * BK * 2, B_BYTES = TN * BK * 2;     // operand tiles: rows x 128 bytes
+    constexpr int A_PPW = TM / 32, B_PPW = TN / 32;                  // 1-KiB pieces (8 rows) per wave
+    constexpr int MI = TM / 32, NI = TN / 32;                        // 16 x 16 units per wave (waves as 2 x 2)
+    constexpr int EPI_BYTES = TM * TN * 4;
+    constexpr int SMEM = 2 * (A_BYTES + B_BYTES) > EPI_BYTES ? 2 * (A_BYTES + B_BYTES) : EPI_BYTES;
+    __shared__ __attribute__((aligned(16))) char smem[SMEM];        // A0 A1 B0 B1 (then the epilogue image)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -47,19 +53,25 @@ __global__ __launch_bounds__(256) void gemm_nt_128(const GemmParams p) {
     // ---- staging addresses: wave w, piece i covers tile rows (w*4+i)*8 .. +8, lane -> (row, 16-B slot)
     const int srow = lane >> 3;
     const int sslot = lane & 7;
-    const T *a_src[4];
-    const T *b_src[4];
-    int s_koff[4];
+    const T *a_src[A_PPW];
+    const T *b_src[B_PPW];
+    int a_koff[A_PPW], b_koff[B_PPW];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = (wave * 4 + i) * 8 + srow;          // row inside the tile
+    for (int i = 0; i < A_PPW; ++i) {
+        const int r = (wave * A_PPW + i) * 8 + srow;       // row inside the tile
         const int c = sslot ^ ((r >> 1) & 7);              // source chunk that lands in this slot
-        s_koff[i] = c * 8;
-        int gm = tile_m * BM + r;
+        a_koff[i] = c * 8;
+        int gm = tile_m * TM + r;
         gm = gm < p.M ? gm : p.M - 1;
-        int gn = tile_n * BN + r;
-        gn = gn < p.N ? gn : p.N - 1;
         a_src[i] = A + (int64_t)gm * p.lda + c * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < B_PPW; ++i) {
+        const int r = (wave * B_PPW + i) * 8 + srow;
+        const int c = sslot ^ ((r >> 1) & 7);
+        b_koff[i] = c * 8;
+        int gn = tile_n * TN + r;
+        gn = gn < p.N ? gn : p.N - 1;
         b_src[i] = B + (int64_t)gn * p.ldb + c * 8;
     }
     const T *zsrc = (const T *)g_zero_chunk;
@@ -72,80 +84,83 @@ __global__ __launch_bounds__(256) void gemm_nt_128(const GemmParams p) {
         const int k0 = (kt - pass * nk1) * BK;
         const int64_t dA = pass == 0 ? 0 : (pass == 1 ? p.dA1 : p.dA2);
         const int64_t dB = pass == 0 ? 0 : (pass == 1 ? p.dB1 : p.dB2);
-        char *abase = smem + buf * TILE_BYTES;
-        char *bbase = smem + (2 + buf) * TILE_BYTES;
+        char *abase = smem + buf * A_BYTES;
+        char *bbase = smem + 2 * A_BYTES + buf * B_BYTES;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const bool kin = (k0 + s_koff[i]) < p.K;
-            const T *sa = kin ? (a_src[i] + k0 + dA) : zsrc;
-            const T *sb = kin ? (b_src[i] + k0 + dB) : zsrc;
-            const int piece = (wave * 4 + i) * 1024;
+        for (int i = 0; i < A_PPW; ++i) {
+            const T *sa = (k0 + a_koff[i]) < p.K ? (a_src[i] + k0 + dA) : zsrc;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)sa,
-                                             (__attribute__((address_space(3))) void *)(abase + piece), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void *)(abase + (wave * A_PPW + i) * 1024),
+                                             16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < B_PPW; ++i) {
+            const T *sb = (k0 + b_koff[i]) < p.K ? (b_src[i] + k0 + dB) : zsrc;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)sb,
-                                             (__attribute__((address_space(3))) void *)(bbase + piece), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void *)(bbase + (wave * B_PPW + i) * 1024),
+                                             16, 0, 0);
         }
     };
 
-    f32x4 acc[4][4];
+    f32x4 acc[MI][NI];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     // ---- fragment read addresses (bytes inside a tile): row = base16 + (lane&15), chunk = ks*4 + (lane>>4)
     const int frow = lane & 15;
     const int fswz = (frow >> 1) & 7;
     const int fchunk = lane >> 4;
-    int a_off[4], b_off[4];
+    int a_off[MI], b_off[NI];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        a_off[i] = (wm * 64 + i * 16 + frow) * 128;
-        b_off[i] = (wn * 64 + i * 16 + frow) * 128;
-    }
+    for (int i = 0; i < MI; ++i) a_off[i] = (wm * (TM / 2) + i * 16 + frow) * 128;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) b_off[i] = (wn * (TN / 2) + i * 16 + frow) * 128;
 
     stage(0, 0);
     for (int kt = 0; kt < nk; ++kt) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
-        const char *abase = smem + (kt & 1) * TILE_BYTES;
-        const char *bbase = smem + (2 + (kt & 1)) * TILE_BYTES;
+        const char *abase = smem + (kt & 1) * A_BYTES;
+        const char *bbase = smem + 2 * A_BYTES + (kt & 1) * B_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int coff = ((ks * 4 + fchunk) ^ fswz) << 4;
-            V8 af[4], bf[4];
+            V8 af[MI], bf[NI];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                af[i] = *(const V8 *)(abase + a_off[i] + coff);
-                bf[i] = *(const V8 *)(bbase + b_off[i] + coff);
-            }
+            for (int i = 0; i < MI; ++i) af[i] = *(const V8 *)(abase + a_off[i] + coff);
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
+            for (int i = 0; i < NI; ++i) bf[i] = *(const V8 *)(bbase + b_off[i] + coff);
 #pragma unroll
-                for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = Op<DT>::mfma16(bf[ni], af[mi], acc[mi][ni]);
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = Op<DT>::mfma16(bf[ni], af[mi], acc[mi][ni]);
         }
     }
 
     // ---- epilogue through LDS: the accumulators (lane = one row, 4 consecutive columns) are parked in a
-    // [128][128] fp32 image (16-byte chunks XOR-swizzled by row, conflict-free both ways) so that the
+    // [TM][TN] fp32 image (16-byte chunks XOR-swizzled by row, conflict-free both ways) so that the
     // bias / GELU / residual / store pass walks whole rows: a wave touches 2 rows x 512 contiguous bytes
     // (fp32) or 2 rows x 256 bytes (16-bit) per instruction instead of 16 rows x 64 bytes.
     __syncthreads();  // every wave is done reading the last operand tile
     float *cs = (float *)smem;
+    constexpr int CPR = TN / 4;  // 16-byte chunks per image row (32 or 16)
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-        const int ml = wm * 64 + mi * 16 + (lane & 15);
+    for (int mi = 0; mi < MI; ++mi) {
+        const int ml = wm * (TM / 2) + mi * 16 + (lane & 15);
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-            const int c = wn * 16 + ni * 4 + (lane >> 4);
-            *(f32x4 *)(cs + ml * BN + ((c ^ (ml & 31)) << 2)) = acc[mi][ni];
+        for (int ni = 0; ni < NI; ++ni) {
+            const int c = wn * (CPR / 2) + ni * 4 + (lane >> 4);
+            *(f32x4 *)(cs + ml * TN + ((c ^ (ml & (CPR - 1))) << 2)) = acc[mi][ni];
         }
     }
     __syncthreads();
     const int64_t coffz = zb * p.sCb + zh * p.sCh;
-    const int c = tid & 31;
-    const int n0 = tile_n * BN + c * 4;
+    const int c = tid & (CPR - 1);
+    constexpr int RPI = 256 / CPR;  // rows per pass of the 256 threads (8 or 16)
+    const int n0 = tile_n * TN + c * 4;
     if (n0 < p.n_store) {
         const bool nfull = n0 + 3 < p.N;
         f32x4 bias_n = {0.f, 0.f, 0.f, 0.f};
@@ -159,11 +174,11 @@ __global__ __launch_bounds__(256) void gemm_nt_128(const GemmParams p) {
             }
         }
 #pragma unroll 4
-        for (int it = 0; it < 16; ++it) {
-            const int ml = it * 8 + (tid >> 5);
-            const int m = tile_m * BM + ml;
+        for (int it = 0; it < TM / RPI; ++it) {
+            const int ml = it * RPI + tid / CPR;
+            const int m = tile_m * TM + ml;
             if (m >= p.M) break;  // rows are visited in increasing order
-            f32x4 v = *(const f32x4 *)(cs + ml * BN + ((c ^ (ml & 31)) << 2));
+            f32x4 v = *(const f32x4 *)(cs + ml * TN + ((c ^ (ml & (CPR - 1))) << 2));
             const float bias_m = (p.bias_mode == 2) ? p.bias[m] : 0.f;
             const float *rrow = nullptr;
             if (p.R) {
@@ -390,13 +405,27 @@ int gemm_nt_launch(const pio_gemm_t &g, hipStream_t s) {
         }
     }
     ProfScope prof(attn ? PROF_GEMM_ATTN : PROF_GEMM_SMALL, algo_flops, algo_bytes, s);  // kernel gemm_nt_128
-    if (g.dtype == PIO_DT_F16) {
-        if (attn) hipLaunchKernelGGL((gemm_nt_128<PIO_DT_F16, 1>), grid, block, 0, s, p);
-        else      hipLaunchKernelGGL((gemm_nt_128<PIO_DT_F16, 0>), grid, block, 0, s, p);
-    } else {
-        if (attn) hipLaunchKernelGGL((gemm_nt_128<PIO_DT_BF16, 1>), grid, block, 0, s, p);
-        else      hipLaunchKernelGGL((gemm_nt_128<PIO_DT_BF16, 0>), grid, block, 0, s, p);
+    // 64 x 64 tiles when the 128 x 128 tiling would leave most CUs without a tile (small batches: the 2048-row latent
+    // stack of the flow model at B = 1 has 64 tiles of 128 x 128 per GEMM, 256 of 64 x 64); override 64 forces them
+    const int64_t tiles128 = (int64_t)tiles_m * p.tiles_n * g.batch;
+    const bool small = gemm_kernel_choice() == 64 || (gemm_kernel_choice() == 0 && tiles128 < 192);
+    if (small) {
+        p.tiles_n = (p.n_store + 63) / 64;
+        grid = dim3((unsigned)(((g.M + 63) / 64) * p.tiles_n), (unsigned)g.batch, 1);
     }
+#define PIO_G128(DTV, KINDV)                                                                            \
+    do {                                                                                                \
+        if (small) hipLaunchKernelGGL((gemm_nt_128<DTV, KINDV, 64, 64>), grid, block, 0, s, p);         \
+        else hipLaunchKernelGGL((gemm_nt_128<DTV, KINDV, 128, 128>), grid, block, 0, s, p);             \
+    } while (0)
+    if (g.dtype == PIO_DT_F16) {
+        if (attn) PIO_G128(PIO_DT_F16, 1);
+        else PIO_G128(PIO_DT_F16, 0);
+    } else {
+        if (attn) PIO_G128(PIO_DT_BF16, 1);
+        else PIO_G128(PIO_DT_BF16, 0);
+    }
+#undef PIO_G128
     return launch_status();
 }
 

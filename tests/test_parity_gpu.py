@@ -175,6 +175,24 @@ def test_gemm_nt_wide(dev, shape, dt):
     _gemm_case(dev, shape, dt, shape[-1], "wide")
 
 
+TILE_SHAPES = [
+    # (same fields) small / ragged problems on BOTH instantiations of the 128-tile kernel: 128x128 tiles (override 128)
+    # and the 64x64 tiles small batches get automatically (override 64)
+    (300, 264, 1024, 1, 1, 0, True, True, True, False, 0),        # fp32 + residual, two-pass weights, ragged
+    (2048, 512, 512, 1, 1, 1, False, False, False, False, 0),     # a flow-model latent projection at B = 1, GELU
+    (100, 72, 40, 3, 1, 0, False, False, False, True, 0),         # batched, hi + lo outputs, K < one tile
+    (65, 65, 8, 1, 0, 0, False, True, False, False, 0),           # one row / column past a 64 tile
+]
+
+
+@pytest.mark.parametrize("tile", [64, 128])
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("shape", TILE_SHAPES)
+def test_gemm_nt_tile_sizes(dev, shape, dt, tile):
+    """gemm_nt_128<.., 128, 128> and <.., 64, 64> against torch fp64 on the same operands."""
+    _gemm_case(dev, shape, dt, tile, f"tile {tile}")
+
+
 @pytest.mark.parametrize("dt", ["f16", "bf16"])
 @pytest.mark.parametrize("shape", STREAM_SHAPES)
 def test_gemm_nt_stream(dev, shape, dt):
