@@ -19,6 +19,10 @@ SHAPES = {  # name: heads, dk, dv, B, Tq, Tk, q_in, kv_in, broadcast q
     "multimodal_dec": (1, 512, 512, 1, 6288, 784, 1026, 512, False),
     "language_enc": (8, 32, 160, 32, 256, 2048, 1280, 768, True),
     "language_dec": (8, 32, 96, 32, 2048, 256, 768, 1280, True),
+    # the latent self-attend shape of the ImageNet model through the CROSS-attention kernel (an all-ones key mask routes
+    # it there) -- for comparison with flash_attn_kernel on the same shape ("sa_flash")
+    "sa_xattn": (8, 128, 128, 32, 512, 512, 1024, 1024, False),
+    "sa_flash": (8, 128, 128, 32, 512, 512, 1024, 1024, False),
 }
 
 
@@ -38,8 +42,11 @@ def main():
         out = torch.empty((B, Tq, q_in), device=dev)
         ws = R.workspace(dev, lib.pio_attention_workspace_bytes(d, B, Tq, Tk))
 
+        km = torch.ones(B, Tk, dtype=torch.uint8, device=dev) if name == "sa_xattn" else None
+
         def call():
-            L.check(lib.pio_attention_fwd(d, R.tensor3(xq), R.tensor3(xkv), R.tensor3(xkv), None, None, None, None,
+            L.check(lib.pio_attention_fwd(d, R.tensor3(xq), R.tensor3(xkv), R.tensor3(xkv),
+                                          km.data_ptr() if km is not None else None, None, None, None,
                                           out.data_ptr(), None, ws.data_ptr(), ws.numel(), R.stream_ptr(dev)), "fwd")
         for _ in range(3):
             call()
