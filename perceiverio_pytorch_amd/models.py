@@ -165,6 +165,7 @@ class FlowPerceiver(nn.Module):
         self.mixed_precision = mixed_precision
         self._flow_scale_factor = flow_scale_factor
         self.query_shard = None      # (rank, world): decode this rank's query rows only + all-gather (dist.py)
+        self.tiles_per_call = 4      # test-mode tiling: tiles batched per forward (1 = the reference's one at a time)
         prep = ImagePreprocessor(img_size=img_size, input_channels=3 * 3 ** 2, prep_type="patches",
                                  spatial_downsample=1, temporal_downsample=2, conv_after_patching=True,
                                  num_channels=64, n_extra_pos_mlp=0, position_encoding_type=PosEncodingType.FOURIER,
@@ -217,12 +218,22 @@ class FlowPerceiver(nn.Module):
         yy, xx = torch.meshgrid(torch.arange(self.H), torch.arange(self.W), indexing="ij")
         ramp = torch.minimum(torch.minimum(xx + 1, self.W - xx), torch.minimum(yy + 1, self.H - yy))
         ramp = (ramp / ramp.max())[None, None].to(image1.device)
+        # Tiles are independent samples: `tiles_per_call` of them go through the model as ONE batch (the reference runs
+        # them one at a time, flow_perceiver.py:165-190) -- same flows, blended in the same order, with the latent
+        # stack's GEMMs seeing tiles_per_call x 2048 rows instead of 2048.
         total, weight = 0, 0
-        for y, x in self.compute_grid_indices((h, w), min_overlap):
-            flow = self._predict_patch(pair[..., y:y + self.H, x:x + self.W])
-            pad = (x, w - x - self.W, y, h - y - self.H)
-            total = total + F.pad(flow * ramp, pad)
-            weight = weight + F.pad(ramp, pad)
+        corners = list(self.compute_grid_indices((h, w), min_overlap))
+        b = pair.shape[0]
+        step = max(1, int(self.tiles_per_call))
+        for i in range(0, len(corners), step):
+            group = corners[i:i + step]
+            tiles = torch.cat([pair[..., y:y + self.H, x:x + self.W] for y, x in group], dim=0)
+            flows = self._predict_patch(tiles)
+            for j, (y, x) in enumerate(group):
+                flow = flows[j * b:(j + 1) * b]
+                pad = (x, w - x - self.W, y, h - y - self.H)
+                total = total + F.pad(flow * ramp, pad)
+                weight = weight + F.pad(ramp, pad)
         return total / weight
 
 

@@ -158,7 +158,10 @@ def test_model_outputs_match_reference(name, policy):
             _close(y[:, :, ::8, ::8], g["out_sub"], name, tol, absmax=g["out_absmax"])
         elif c["cls"] == "FlowPerceiver":
             _close(model(ins[0][..., :48, :64], ins[1][..., :48, :64]), g["out_train"], name + " train", tol)
-            _close(model(ins[0], ins[1], test_mode=True, min_overlap=10), g["out_test"], name + " tiled", tol)
+            y_tiled = model(ins[0], ins[1], test_mode=True, min_overlap=10)       # tiles batched 4 per forward
+            _close(y_tiled, g["out_test"], name + " tiled", tol)
+            model.tiles_per_call = 1                                              # the reference's one tile at a time
+            _close(model(ins[0], ins[1], test_mode=True, min_overlap=10), g["out_test"], name + " tiled, 1 per call", tol)
         elif c["cls"] == "MultiModalPerceiver":
             if policy == "fp16x2w":
                 tol = 2e-3     # characterisation (dense reconstruction, single-fp16 decoder + heads): see flow_full above
