@@ -1096,3 +1096,30 @@ def test_fused_cross_attention_fuzz(dev):
         ym = m(xq_t, _t(xkv, dev), _t(xkv, dev), attention_mask=_t(mask3, dev))
         assert torch.isfinite(y).all(), (it, H, dk, dv, B, Tq, Tk, mk)
         _assert_close(y, ym.detach().cpu().numpy(), TOL, what=f"fuzz {it}: H={H} dk={dk} dv={dv} B={B} Tq={Tq} Tk={Tk} {mk}")
+
+
+def test_fused_cross_attention_is_deterministic(dev):
+    """The cross-attention kernel's LDS ring runs on COUNTED waits and raw barriers: a miscounted wait would show as a
+    run-to-run difference.  Thirty launches per shape (ragged piece shares, key splits, every ring depth) under uneven
+    load must agree bit for bit."""
+    from perceiverio_pytorch_amd.transformer_primitives import Attention
+    rng = np.random.default_rng(7)
+    _policy("fp16")
+    for (H, dk, dv, B, Tq, Tk) in [(1, 322, 322, 3, 300, 3000), (1, 704, 704, 1, 200, 5000), (1, 512, 512, 2, 257, 700),
+                                   (8, 32, 160, 2, 256, 2048), (8, 32, 96, 1, 130, 999), (2, 128, 128, 5, 100, 640)]:
+        q_in, kv_in = 64, 96
+        p = O.gen_attention("", q_in, kv_in, H * dk, H * dv, q_in, seed=dk + Tk)
+        m = Attention(q_in, kv_in, kv_in, num_heads=H, qk_out_channels=H * dk, v_out_channels=H * dv,
+                      output_channels=q_in)
+        m.load_state_dict(_sd(p, "cpu"))
+        m = m.to(dev).eval()
+        xq = _t(rng.standard_normal((B, Tq, q_in)).astype(np.float32), dev)
+        xkv = _t(rng.standard_normal((B, Tk, kv_in)).astype(np.float32), dev)
+        km = rng.random((B, Tk)) > 0.2
+        first = _attention_vector_masks(m, xq, xkv, km, None, dev).clone()
+        noise = torch.randn(4096, 4096, device=dev)
+        for it in range(30):
+            if it % 3 == 0:
+                noise = noise @ noise.T * 1e-4          # something else keeps part of the chip busy
+            y = _attention_vector_masks(m, xq, xkv, km, None, dev)
+            assert torch.equal(y, first), f"run {it} differs for H={H} dk={dk} dv={dv} B={B} Tq={Tq} Tk={Tk}"
