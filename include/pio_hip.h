@@ -211,6 +211,14 @@ int pio_layernorm_cast(const pio_tensor3_t *x, const pio_layernorm_t *ln, void *
 int pio_layernorm_cast_cat(const pio_tensor3_t *x1, const pio_tensor3_t *x2, const pio_layernorm_t *ln, void *y,
                            void *y_lo, int32_t c_pad, int32_t dtype, void *stream);
 
+/* Tail of Conv2DDownsample (processor_utils.py:163-180) in one pass over the conv's output x [B,C,H,W] fp32:
+ * y[b, oh*OW + ow, c] = max over the 3x3 stride-2 TF-"SAME" window of relu(x * scale[c] + shift[c]) -- eval-mode
+ * BatchNorm folded into (scale, shift) = (gamma / sqrt(var + eps), beta - mean * scale), or (1, 0) without one.
+ * OH = ceil(H/2), OW = ceil(W/2); pad_top / pad_left = the leading SAME padding (0 or 1).  y is the channels-last token
+ * array [B, OH*OW, C] the encoder consumes.  W <= 212. */
+int pio_bn_relu_maxpool_tokens(const float *x, const float *scale, const float *shift, float *y, int32_t B, int32_t C,
+                               int32_t H, int32_t W, int32_t pad_top, int32_t pad_left, void *stream);
+
 /* C = epilogue(alpha * A B^T): A [M,K], B [N,K] operand dtype, K contiguous (multiple of 8).
  * Batched over z = zb*nh + zh with element strides; bias_mode 0 none / 1 per column / 2 per row;
  * act 0 none / 1 exact-erf GELU (F.gelu, transformer_primitives.py:214); optional fp32 residual R

@@ -102,6 +102,7 @@ SIGNATURES = {
     "pio_pack_linear": (C.c_int, [_vp, _vp, _i32, _i32, _i64, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "pio_layernorm_cast": (C.c_int, [P(Tensor3), P(LayerNorm), _vp, _vp, _i32, _i32, _vp]),
     "pio_layernorm_cast_cat": (C.c_int, [P(Tensor3), P(Tensor3), P(LayerNorm), _vp, _vp, _i32, _i32, _vp]),
+    "pio_bn_relu_maxpool_tokens": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "pio_gemm_nt": (C.c_int, [P(Gemm), _vp]),
     "pio_softmax_rows": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _f, _vp, _vp, _vp, _vp, _i32, _vp]),
     "pio_attention_workspace_bytes": (_sz, [P(Attention), _i32, _i32, _i32]),

@@ -155,6 +155,11 @@ int pio_layernorm_cast_cat(const pio_tensor3_t *x1, const pio_tensor3_t *x2, con
     return layernorm_cast_cat_launch(*x1, *x2, *ln, y, y_lo, c_pad, dtype, (hipStream_t)stream);
 }
 
+int pio_bn_relu_maxpool_tokens(const float *x, const float *scale, const float *shift, float *y, int32_t B, int32_t C,
+                               int32_t H, int32_t W, int32_t pad_top, int32_t pad_left, void *stream) {
+    return bn_relu_pool_nhwc_launch(x, scale, shift, y, B, C, H, W, pad_top, pad_left, (hipStream_t)stream);
+}
+
 int pio_gemm_nt(const pio_gemm_t *g, void *stream) {
     if (!g) return PIO_E_ARG;
     return gemm_nt_launch(*g, (hipStream_t)stream);

@@ -117,6 +117,9 @@ int xattn_launch(int dtype, int dkp, int dvp, int dk_logical, const void *Q, con
                  void *O_lo, int B, int H, int Tq, int Tk, int64_t ldq, int64_t ldk, int64_t ldvt, int64_t ldo, int64_t sQb,
                  int64_t sKb, int64_t sVb, int64_t sOb, const uint8_t *kv_mask, const uint8_t *q_mask, void *partials,
                  hipStream_t s);
+// eval BatchNorm -> ReLU -> 3x3/2 SAME max-pool -> channels-last tokens (tail of Conv2DDownsample)
+int bn_relu_pool_nhwc_launch(const float *x, const float *scale, const float *shift, float *y, int B, int C, int H, int W,
+                             int pad_top, int pad_left, hipStream_t s);
 int pack_linear_launch(const float *w, const float *bias, int out, int in, int64_t ldw, int row_heads,
                        int col_heads, void *dst_hi, void *dst_lo, float *dst_bias, int dst_row0, int k_pad,
                        int dtype, hipStream_t s);

@@ -135,6 +135,42 @@ class Conv2DDownsample(nn.Module):
             x = F.max_pool2d(F.pad(x, same_padding(x.shape[1:], 3, 2)), kernel_size=3, stride=2)
         return x
 
+    def forward_tokens(self, inputs: torch.Tensor):
+        """The same network with its LAST layer's BatchNorm -> ReLU -> max-pool -> channels-last reshape done by ONE
+        HIP kernel (pio_bn_relu_maxpool_tokens): returns the token array [B, OH*OW, C] directly, or None when this
+        configuration is not covered (CPU tensor, training-mode BatchNorm, maps wider than 212)."""
+        if not inputs.is_cuda or inputs.dim() != 4 or (self.norms is not None and self.training):
+            return None
+        from . import _lib as L
+        from . import runtime as R
+        x = inputs
+        last = len(self.convs) - 1
+        for layer, conv in enumerate(self.convs):
+            x = conv(F.pad(x, same_padding(x.shape[1:], conv.kernel_size, conv.stride)))
+            if layer < last:
+                if self.norms is not None:
+                    x = self.norms[layer](x)
+                x = F.max_pool2d(F.pad(F.relu(x), same_padding(x.shape[1:], 3, 2)), kernel_size=3, stride=2)
+        x = x.float().contiguous()
+        b, c, h, w = x.shape
+        if w > 212:
+            return None
+        if self.norms is not None:
+            bn = self.norms[last]
+            scale = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).float()
+            shift = (bn.bias - bn.running_mean * scale).float()
+        else:
+            scale = torch.ones(c, device=x.device)
+            shift = torch.zeros(c, device=x.device)
+        pads = same_padding(x.shape[1:], 3, 2)          # [left, right, top, bottom]
+        y = torch.empty((b, ((h + 1) // 2) * ((w + 1) // 2), c), dtype=torch.float32, device=x.device)
+        with R.on_device(x.device):
+            L.check(L.lib().pio_bn_relu_maxpool_tokens(x.data_ptr(), scale.contiguous().data_ptr(),
+                                                       shift.contiguous().data_ptr(), y.data_ptr(), b, c, h, w,
+                                                       pads[2], pads[0], R.stream_ptr(x.device)),
+                    "pio_bn_relu_maxpool_tokens")
+        return R.forward_only(y, inputs, *self.parameters())
+
 
 # ---------------------------------------------------------------------------------------------------
 # preprocessors: forward(inputs, *, pos=None) -> (inputs_with_pos [B,M,C], inputs_without_pos); n_output_channels()
@@ -256,6 +292,10 @@ class ImagePreprocessor(nn.Module, _PosMixin):
 
     def _features(self, inputs: torch.Tensor) -> torch.Tensor:
         x = inputs
+        if self._prep_type == "conv" and x.dim() == 4:
+            tokens = self.convnet.forward_tokens(x)      # conv (MIOpen) + one fused HIP pass, channels-last tokens
+            if tokens is not None:
+                return tokens
         if self._prep_type in ("conv", "conv1x1"):
             video = x.dim() == 5
             if video:
