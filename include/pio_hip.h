@@ -12,7 +12,7 @@
  *   - every pointer is a DEVICE pointer owned by the caller; compute calls allocate and free nothing and
  *     keep no state between calls => they are thread-safe per (stream, workspace).  The only process-wide
  *     mutable state is opt-in tooling, none of it thread-safe: the per-launch profiler (pio_prof_*) and the
- *     A/B switches pio_ln_fold_enable / pio_gemm_kernel_override / pio_set_cu_budget (set them before
+ *     A/B switches pio_ln_fold_enable / pio_gemm_kernel_override / pio_flash_variant_override / pio_set_cu_budget (set them before
  *     concurrent use).
  *   - scratch memory is caller-provided: query pio_*_workspace_bytes() first.
  *   - tensors at the boundary are float32, last dimension contiguous; batch / row strides are given
@@ -169,6 +169,11 @@ int pio_ln_fold_enable(int on);
  * it is legal, 3: the LayerNorm-fold producer on the two-workgroups-per-CU kernel (gemm_nt_duo).  Returns the
  * previous setting. */
 int pio_gemm_kernel_override(int which);
+/* Variant of the fused self-attention kernel on its hot shape (128-wide heads, V row-major out of the fused q|k|v GEMM,
+ * >= 256 queries): 0 = lock-step waves (default; env PIO_FLASH_VARIANT gives the initial value), 1 = one wave per SIMD
+ * with the softmax arithmetic issued in the shadow of the MFMAs, 2 = two staggered wave groups.  Any other value only
+ * reads.  Returns the previous setting. */
+int pio_flash_variant_override(int which);
 
 /* --- running on a part of the chip ----------------------------------------------------------------- */
 /* A stream whose kernels run only on the CUs whose bit is set in `mask` (`words` 32-bit words; bit i = CU i / 8 of

@@ -80,11 +80,11 @@ __device__ __forceinline__ void xa_mfma_v(f32x16 &c, typename Op<DT>::V8 a, type
 template <int DT, bool B_IN_AGPR>
 __device__ __forceinline__ void xa_mfma_v0(f32x16 &c, typename Op<DT>::V8 a, typename Op<DT>::V8 b) {  // c = a b
     if constexpr (DT == PIO_DT_F16) {
-        if constexpr (B_IN_AGPR) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=v"(c) : "v"(a), "a"(b));
-        else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=v"(c) : "v"(a), "v"(b));
+        if constexpr (B_IN_AGPR) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(c) : "v"(a), "a"(b));
+        else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(c) : "v"(a), "v"(b));
     } else {
-        if constexpr (B_IN_AGPR) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(c) : "v"(a), "a"(b));
-        else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(c) : "v"(a), "v"(b));
+        if constexpr (B_IN_AGPR) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(c) : "v"(a), "a"(b));
+        else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(c) : "v"(a), "v"(b));
     }
 }
 template <int DT>

@@ -1153,3 +1153,32 @@ def test_conv_downsample_fused_tail_matches_torch_ops(dev, shape, channels, laye
     torch.testing.assert_close(got, want, rtol=2e-5, atol=2e-6)
     net.train()
     assert (net.forward_tokens(x) is None) == bn          # training-mode BatchNorm is not folded
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("shape", [(2, 256), (3, 512), (2, 1024), (2, 777), (16, 640)])
+def test_self_attention_kernel_variants_agree(dev, variant, shape):
+    """pio_flash_variant_override: the one-wave-per-SIMD pipelined kernel (1) and the staggered-groups kernel (2) against
+    the default lock-step kernel (0) on the hot shape (1024-channel SelfAttention block, 8 heads of 128, V row-major):
+    same operands, same P rounding (16 bit), different summation order / softmax reference point -> a few 1e-4 of the
+    output scale.  Shapes a variant does not take (odd tile counts, ragged key tails) fall back to variant 0: equal."""
+    import perceiverio_pytorch_amd as P
+    from perceiverio_pytorch_amd import _lib as L
+    from perceiverio_pytorch_amd.transformer_primitives import SelfAttention
+    lib = L.lib()
+    _policy("fp16")
+    B, T = shape
+    torch.manual_seed(T)
+    m = SelfAttention(1024, widening_factor=1, num_heads=8).to(dev).eval()
+    x = torch.randn(B, T, 1024, device=dev) * 1.5 + 0.2
+    prev = lib.pio_flash_variant_override(0)
+    try:
+        y0 = m(x).double()
+        assert lib.pio_flash_variant_override(variant) == 0
+        y1 = m(x).double()
+    finally:
+        lib.pio_flash_variant_override(prev)
+    scale = y0.abs().max()
+    assert ((y1 - y0).abs().max() / scale).item() <= 3e-4, f"variant {variant} {shape}"
+    assert ((y1 - y0).norm() / y0.norm()).item() <= 2e-4

@@ -1,27 +1,39 @@
-"""Per-kernel timing of one latent self-attend layer (SelfAttention module, ImageNet shape 32 x 512 x 1024, 8 heads); prints the per-class profiler numbers (dev tool; A/B two builds with PIO_LIB_PATH)."""
+"""Dev tool (GPU): device time of the fused SELF-attention kernel on the hot shape (B x 512 latents x 8 heads of 128,
+V row-major out of the fused q|k|v GEMM).  PIO_FLASH_PIPE=0 selects the lock-step 8-wave kernel for comparison."""
 import ctypes as C
 import os
 import sys
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-import torch
-import perceiverio_pytorch_amd as P
-from perceiverio_pytorch_amd import _lib as L
-from perceiverio_pytorch_amd.transformer_primitives import SelfAttention
 
-lib = L.lib()
-dev = torch.device("cuda:0")
-B, T, D, H = 32, 512, 1024, 8
-m = SelfAttention(D, num_heads=H, widening_factor=1).to(dev).eval()
-x = torch.randn(B, T, D, device=dev)
-P.set_precision_policy("fp16")
-with torch.inference_mode():
-    for _ in range(3):
-        m(x)
-    torch.cuda.synchronize()
-    L.check(lib.pio_prof_begin(4096))
-    for _ in range(20):
-        m(x)
-    ms = (C.c_double * 9)(); fl = (C.c_double * 9)(); by = (C.c_double * 9)(); ln = (C.c_int64 * 9)()
-    lib.pio_prof_end(ms, fl, by, ln)
-names = ["gemm256", "gemm128b", "ln", "softmax", "pack", "flash", "gemm128", "stream"]
-print(" ".join(f"{n}={ms[i] / ln[i] * 1e3:.1f}us(x{ln[i]})" for i, n in enumerate(names) if ln[i]), flush=True)
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path[:0] = [ROOT]
+import torch  # noqa: E402
+import perceiverio_pytorch_amd as P  # noqa: E402
+from perceiverio_pytorch_amd import _lib as L  # noqa: E402
+from perceiverio_pytorch_amd.transformer_primitives import SelfAttention  # noqa: E402
+
+
+def main():
+    lib = P.lib()
+    dev = torch.device("cuda:0")
+    P.set_precision_policy("fp16")
+    for B, T in ((32, 512), (32, 1024), (4, 512)):
+        m = SelfAttention(1024, widening_factor=1, num_heads=8).to(dev).eval()
+        x = torch.randn(B, T, 1024, device=dev)
+        with torch.no_grad():
+            for _ in range(3):
+                y = m(x)
+            torch.cuda.synchronize()
+            n = 20
+            L.check(lib.pio_prof_begin(4096))
+            for _ in range(n):
+                m(x)
+            ms = (C.c_double * 9)(); fl = (C.c_double * 9)(); by = (C.c_double * 9)(); ln = (C.c_int64 * 9)()
+            lib.pio_prof_end(ms, fl, by, ln)
+        us = ms[5] / n * 1e3
+        print(f"B={B} T={T}: fused self-attention {us:8.1f} us ({fl[5] / n / (us * 1e-6) / 1e12:7.1f} algorithmic "
+              f"TFLOP/s, {ln[5] // n} launches) PIO_FLASH_PIPE={os.environ.get('PIO_FLASH_PIPE', '1')} "
+              f"checksum {float(y.double().abs().mean()):.6f}", flush=True)
+
+
+if __name__ == "__main__":
+    main()
