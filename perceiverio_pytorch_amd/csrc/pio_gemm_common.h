@@ -37,21 +37,42 @@ struct GemmParams {
 };
 
 
-// erf by Abramowitz & Stegun 7.1.26 (|abs error| <= 1.5e-7, i.e. fp32-level for GELU): one v_exp, one v_rcp and
-// a 5-term polynomial instead of libm's branchy erff (which cost ~20 % of a K=1024 GEMM's time in the epilogue).
-__device__ __forceinline__ float fast_erf(float x) {
-    const float ax = fabsf(x);
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
-    float poly = fmaf(1.061405429f, t, -1.453152027f);
-    poly = fmaf(poly, t, 1.421413741f);
-    poly = fmaf(poly, t, -0.284496736f);
-    poly = fmaf(poly, t, 0.254829592f);
-    poly *= t;
-    const float e = __builtin_amdgcn_exp2f(-ax * ax * 1.4426950408889634f);
-    const float r = 1.0f - poly * e;
-    return copysignf(r, x);
+// Exact (erf) GELU, gelu(x) = x Phi(x), in eight instruction slots per element: with E = Phi(-|x|) = 0.5 erfc(|x| / sqrt 2)
+//     gelu(x) = max(x, 0) - |x| E        (x >= 0: x (1 - E);  x < 0: x E)
+// and log2 E is smooth enough for a degree-7 polynomial in a = min(|x|, 6) (weighted minimax fit, weight |x| E = the
+// sensitivity of the result; beyond 6, |x| E < 6e-9).  One v_exp_f32, no v_rcp_f32, no sign transfer.  Max |error| in
+// fp32 over [-10, 10]: 2.6e-7 absolute (the A&S 7.1.26 form it replaces -- v_rcp + v_exp + 5-term polynomial, ~20
+// slots with the hazard padding of two dependent transcendentals: 4.6e-7); the epilogues that call it are bound by the
+// number of instructions a single wave can issue, not by their memory traffic.  tools/gelu_fit.py makes the table.
+__device__ __forceinline__ float gelu_erf(float x) {
+    const float a = fminf(fabsf(x), 6.0f);
+    float q = 3.152013050566893e-06f;
+    q = fmaf(q, a, 2.9346412588893145e-07f);
+    q = fmaf(q, a, -0.0006359288236126304f);
+    q = fmaf(q, a, 0.007810706272721291f);
+    q = fmaf(q, a, -0.05312380567193031f);
+    q = fmaf(q, a, -0.45892834663391113f);
+    q = fmaf(q, a, -1.15116286277771f);
+    q = fmaf(q, a, -0.9999961256980896f);
+    return fmaf(-fabsf(x), __builtin_amdgcn_exp2f(q), fmaxf(x, 0.0f));
 }
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752440f)); }
+// Two elements at once with the polynomial on packed fp32 FMAs (coefficients in register pairs): 7.5 slots per element.
+typedef float pio_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ pio_f32x2 gelu_erf2(pio_f32x2 x) {
+    const pio_f32x2 a = {fminf(fabsf(x[0]), 6.0f), fminf(fabsf(x[1]), 6.0f)};
+    pio_f32x2 q = {3.152013050566893e-06f, 3.152013050566893e-06f};
+    q = __builtin_elementwise_fma(q, a, (pio_f32x2){2.9346412588893145e-07f, 2.9346412588893145e-07f});
+    q = __builtin_elementwise_fma(q, a, (pio_f32x2){-0.0006359288236126304f, -0.0006359288236126304f});
+    q = __builtin_elementwise_fma(q, a, (pio_f32x2){0.007810706272721291f, 0.007810706272721291f});
+    q = __builtin_elementwise_fma(q, a, (pio_f32x2){-0.05312380567193031f, -0.05312380567193031f});
+    q = __builtin_elementwise_fma(q, a, (pio_f32x2){-0.45892834663391113f, -0.45892834663391113f});
+    q = __builtin_elementwise_fma(q, a, (pio_f32x2){-1.15116286277771f, -1.15116286277771f});
+    q = __builtin_elementwise_fma(q, a, (pio_f32x2){-0.9999961256980896f, -0.9999961256980896f});
+    pio_f32x2 r;
+    r[0] = fmaf(-fabsf(x[0]), __builtin_amdgcn_exp2f(q[0]), fmaxf(x[0], 0.0f));
+    r[1] = fmaf(-fabsf(x[1]), __builtin_amdgcn_exp2f(q[1]), fmaxf(x[1], 0.0f));
+    return r;
+}
 
 
 // bias / activation / residual / store of 4 consecutive output columns (m, n0..n0+3) held in v.

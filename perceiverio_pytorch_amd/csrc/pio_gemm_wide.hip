@@ -630,6 +630,20 @@ __global__ __launch_bounds__(256) void gemm_nt_wide(const GemmParams p, int tile
             if constexpr (ACT == 1) x = gelu_erf(x);
             return x;
         };
+        // four output elements (the epilogue is bound by its instruction count: GELU goes two elements at a time)
+        auto val4 = [&](f32x4 a, f32x4 b, f32x4 c, int mi) {
+            f32x4 x;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if constexpr (LNF == 2) x[r] = a[r] * rs[mi] + (nmr[mi] * c[r] + b[r]);
+                else x[r] = a[r] * p.alpha + b[r];
+            }
+            if constexpr (ACT == 1) {
+                const pio_f32x2 lo = gelu_erf2(pio_f32x2{x[0], x[1]}), hi = gelu_erf2(pio_f32x2{x[2], x[3]});
+                x = f32x4{lo[0], lo[1], hi[0], hi[1]};
+            }
+            return x;
+        };
         if (interior) {
             // interior tile (every column < N <= n_store): one row pointer per mi, the four column groups are
             // immediate offsets of the store
@@ -653,10 +667,17 @@ __global__ __launch_bounds__(256) void gemm_nt_wide(const GemmParams p, int tile
 #pragma unroll
                 for (int pp = 0; pp < 4; ++pp) {
                     V8 h;
+                    f32x4 a0, a1;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        h[r] = Op<DT>::from_f32(val(acc_read(acc[mi][2 * pp][r]), b0[pp][r], c0[pp][r], mi));
-                        h[4 + r] = Op<DT>::from_f32(val(acc_read(acc[mi][2 * pp + 1][r]), b1[pp][r], c1[pp][r], mi));
+                        a0[r] = acc_read(acc[mi][2 * pp][r]);
+                        a1[r] = acc_read(acc[mi][2 * pp + 1][r]);
+                    }
+                    const f32x4 y0 = val4(a0, b0[pp], c0[pp], mi), y1 = val4(a1, b1[pp], c1[pp], mi);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        h[r] = Op<DT>::from_f32(y0[r]);
+                        h[4 + r] = Op<DT>::from_f32(y1[r]);
                     }
                     *(V8 *)(crow + pp * 64) = h;
                     __builtin_amdgcn_sched_barrier(0);  // (else all 256 accumulators are read out before the first store)
