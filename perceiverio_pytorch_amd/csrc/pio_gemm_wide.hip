@@ -452,28 +452,84 @@ __global__ __launch_bounds__(256) void gemm_nt_wide(const GemmParams p, int tile
                         const f32x4 a1 = *(const f32x4 *)(stg + (st * 4 + cr) * ROWP + cc + 4);
                         const V8 hh = rh[mi & 1][st], ll = rl[mi & 1][st];
                         f32x4 x0, x1;
-                        float rsum = 0.f, rsq = 0.f;
+                        float rsum, rsq;
                         V8 h, l;
+                        if constexpr (DT == PIO_DT_F16) {
+                            // This epilogue is bound by the number of instructions one wave can issue (~5 cycles each),
+                            // not by its bytes: the residual halves enter through v_fma_mix_f32 (16-bit operand read in
+                            // place: no unpack + convert), the lo half of the result leaves the same way, the row
+                            // statistics run two columns per instruction, and the 16-lane reduction below uses DPP row
+                            // rotations instead of ds_bpermute.
+                            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                            const u32x4 hw = __builtin_bit_cast(u32x4, hh), lw = __builtin_bit_cast(u32x4, ll);
+                            auto mix_add = [](uint32_t pair, int hi, float t, float sgn) {  // t + sgn * half(pair, hi)
+                                float d;
+                                if (hi) {
+                                    if (sgn > 0) asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(pair), "v"(t));
+                                    else asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(pair), "v"(t));
+                                } else {
+                                    if (sgn > 0) asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(pair), "v"(t));
+                                    else asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(pair), "v"(t));
+                                }
+                                return d;
+                            };
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            x0[r] = a0[r] * p.alpha + bc0[r] + (Op<DT>::to_f32(hh[r]) + Op<DT>::to_f32(ll[r]));
-                            x1[r] = a1[r] * p.alpha + bc1[r] + (Op<DT>::to_f32(hh[4 + r]) + Op<DT>::to_f32(ll[4 + r]));
-                            rsum += x0[r] + x1[r];
-                            rsq += x0[r] * x0[r] + x1[r] * x1[r];
-                            h[r] = Op<DT>::from_f32(x0[r]);
-                            h[4 + r] = Op<DT>::from_f32(x1[r]);
-                            l[r] = Op<DT>::from_f32(x0[r] - Op<DT>::to_f32(h[r]));
-                            l[4 + r] = Op<DT>::from_f32(x1[r] - Op<DT>::to_f32(h[4 + r]));
+                            for (int r = 0; r < 4; ++r) {
+                                float t0 = fmaf(a0[r], p.alpha, bc0[r]), t1 = fmaf(a1[r], p.alpha, bc1[r]);
+                                t0 = mix_add(hw[r >> 1], r & 1, t0, 1.f);
+                                t1 = mix_add(hw[2 + (r >> 1)], r & 1, t1, 1.f);
+                                x0[r] = mix_add(lw[r >> 1], r & 1, t0, 1.f);
+                                x1[r] = mix_add(lw[2 + (r >> 1)], r & 1, t1, 1.f);
+                                h[r] = Op<DT>::from_f32(x0[r]);
+                                h[4 + r] = Op<DT>::from_f32(x1[r]);
+                            }
+                            const u32x4 hp = __builtin_bit_cast(u32x4, h);
+                            pio_f32x2 s2 = {0.f, 0.f}, q2 = {0.f, 0.f};
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                l[r] = Op<DT>::from_f32(mix_add(hp[r >> 1], r & 1, x0[r], -1.f));
+                                l[4 + r] = Op<DT>::from_f32(mix_add(hp[2 + (r >> 1)], r & 1, x1[r], -1.f));
+                                const pio_f32x2 xx = {x0[r], x1[r]};
+                                s2 += xx;
+                                q2 = __builtin_elementwise_fma(xx, xx, q2);
+                            }
+                            rsum = s2[0] + s2[1];
+                            rsq = q2[0] + q2[1];
+                        } else {
+                            rsum = 0.f;
+                            rsq = 0.f;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                x0[r] = a0[r] * p.alpha + bc0[r] + (Op<DT>::to_f32(hh[r]) + Op<DT>::to_f32(ll[r]));
+                                x1[r] = a1[r] * p.alpha + bc1[r] + (Op<DT>::to_f32(hh[4 + r]) + Op<DT>::to_f32(ll[4 + r]));
+                                rsum += x0[r] + x1[r];
+                                rsq += x0[r] * x0[r] + x1[r] * x1[r];
+                                h[r] = Op<DT>::from_f32(x0[r]);
+                                h[4 + r] = Op<DT>::from_f32(x1[r]);
+                                l[r] = Op<DT>::from_f32(x0[r] - Op<DT>::to_f32(h[r]));
+                                l[4 + r] = Op<DT>::from_f32(x1[r] - Op<DT>::to_f32(h[4 + r]));
+                            }
                         }
                         const int64_t ro = (int64_t)(mi * 4 + st) * rstep4;
                         *(V8 *)(x_hi + ro) = h;
                         *(V8 *)(x_lo + ro) = l;
-                        // the 16 lanes of a row hold 8 columns each: four butterfly steps, lane (lane & 15) == 0 writes
-                        // the row's (sum, sum of squares) over this wave's 128-column block
-#pragma unroll
-                        for (int sh = 1; sh < 16; sh <<= 1) {
-                            rsum += __shfl_xor(rsum, sh);
-                            rsq += __shfl_xor(rsq, sh);
+                        // the 16 lanes of a row hold 8 columns each: four rotations inside the 16-lane DPP row leave the
+                        // row's (sum, sum of squares) over this wave's 128-column block in every lane; lane 0 of the
+                        // row writes it
+                        {
+                            auto ror_add = [](float v, auto NC) {
+                                constexpr int n = decltype(NC)::value;
+                                const int moved = __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x120 + n, 0xf, 0xf, true);
+                                return v + __builtin_bit_cast(float, moved);
+                            };
+                            rsum = ror_add(rsum, std::integral_constant<int, 8>{});
+                            rsq = ror_add(rsq, std::integral_constant<int, 8>{});
+                            rsum = ror_add(rsum, std::integral_constant<int, 4>{});
+                            rsq = ror_add(rsq, std::integral_constant<int, 4>{});
+                            rsum = ror_add(rsum, std::integral_constant<int, 2>{});
+                            rsq = ror_add(rsq, std::integral_constant<int, 2>{});
+                            rsum = ror_add(rsum, std::integral_constant<int, 1>{});
+                            rsq = ror_add(rsq, std::integral_constant<int, 1>{});
                         }
                         if ((lane & 15) == 0) {
                             float *dstp = part + (int64_t)(mi * 16 + st * 4) * (p.N >> 7) * 2;

@@ -30,6 +30,7 @@ def main():
             ms = (C.c_double * 9)(); fl = (C.c_double * 9)(); by = (C.c_double * 9)(); ln = (C.c_int64 * 9)()
             lib.pio_prof_end(ms, fl, by, ln)
         us = ms[5] / n * 1e3
+        print("   per class us per forward:", {k: round(ms[k] / n * 1e3, 1) for k in range(9) if ms[k] > 0}, flush=True)
         print(f"B={B} T={T}: fused self-attention {us:8.1f} us ({fl[5] / n / (us * 1e-6) / 1e12:7.1f} algorithmic "
               f"TFLOP/s, {ln[5] // n} launches) PIO_FLASH_PIPE={os.environ.get('PIO_FLASH_PIPE', '1')} "
               f"checksum {float(y.double().abs().mean()):.6f}", flush=True)
