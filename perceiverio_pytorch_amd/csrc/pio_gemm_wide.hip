@@ -420,7 +420,11 @@ __global__ __launch_bounds__(256) void gemm_nt_wide(const GemmParams p, int tile
                 T *const x_lo = (T *)p.X16_lo + (int64_t)(m_w + cr) * p.ld16 + n_c;
                 float *const part = p.row_part + ((int64_t)(m_w + cr) * (p.N >> 7) + (o_n0 >> 7)) * 2;
                 const int64_t rstep4 = 4 * p.ld16;          // elements per 4 rows
-                V8 rh[2][4], rl[2][4];
+                // The residual of row block mi is requested RD blocks ahead: with one block in flight (8 KiB per wave,
+                // 32 KiB per CU) against ~2 us of loaded-memory latency a CU drew 16-19 GB/s -- the whole chip 4.7 TB/s
+                // by lack of requests in flight, not by HBM.
+                constexpr int RD = 2;
+                V8 rh[RD + 1][4], rl[RD + 1][4];
                 auto r_load = [&](int set, int mi) {
 #pragma unroll
                     for (int st = 0; st < 4; ++st) {
@@ -428,10 +432,11 @@ __global__ __launch_bounds__(256) void gemm_nt_wide(const GemmParams p, int tile
                         rl[set][st] = *(const V8 *)(r_lo + (int64_t)(mi * 4 + st) * rstep4);
                     }
                 };
-                r_load(0, 0);
+#pragma unroll
+                for (int mi = 0; mi < RD; ++mi) r_load(mi, mi);
 #pragma unroll
                 for (int mi = 0; mi < 8; ++mi) {
-                    if (mi < 7) r_load((mi + 1) & 1, mi + 1);
+                    if (mi + RD < 8) r_load((mi + RD) % (RD + 1), mi + RD);
                     // accumulators of row block mi -> LDS, accumulator arrangement (row fr, 8 columns at 32 pp + 8 fq)
 #pragma unroll
                     for (int pp = 0; pp < 4; ++pp) {
@@ -450,7 +455,7 @@ __global__ __launch_bounds__(256) void gemm_nt_wide(const GemmParams p, int tile
                     for (int st = 0; st < 4; ++st) {
                         const f32x4 a0 = *(const f32x4 *)(stg + (st * 4 + cr) * ROWP + cc);
                         const f32x4 a1 = *(const f32x4 *)(stg + (st * 4 + cr) * ROWP + cc + 4);
-                        const V8 hh = rh[mi & 1][st], ll = rl[mi & 1][st];
+                        const V8 hh = rh[mi % (RD + 1)][st], ll = rl[mi % (RD + 1)][st];
                         f32x4 x0, x1;
                         float rsum, rsq;
                         V8 h, l;
