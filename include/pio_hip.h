@@ -220,7 +220,7 @@ int pio_layernorm_cast_cat(const pio_tensor3_t *x1, const pio_tensor3_t *x2, con
  * y[b, oh*OW + ow, c] = max over the 3x3 stride-2 TF-"SAME" window of relu(x * scale[c] + shift[c]) -- eval-mode
  * BatchNorm folded into (scale, shift) = (gamma / sqrt(var + eps), beta - mean * scale), or (1, 0) without one.
  * OH = ceil(H/2), OW = ceil(W/2); pad_top / pad_left = the leading SAME padding (0 or 1).  y is the channels-last token
- * array [B, OH*OW, C] the encoder consumes.  W <= 212. */
+ * array [B, OH*OW, C] the encoder consumes. */
 int pio_bn_relu_maxpool_tokens(const float *x, const float *scale, const float *shift, float *y, int32_t B, int32_t C,
                                int32_t H, int32_t W, int32_t pad_top, int32_t pad_left, void *stream);
 

@@ -749,48 +749,50 @@ int softmax_rows_launch(const float *S, int64_t lds, void *P, void *P_lo, int64_
 // ReLU -> 3x3 stride-2 max-pool with TF-"SAME" padding -> channels-last tokens.  x [B, C, H, W] (the 7x7 conv's
 // output) -> y [B, OH * OW, C], the layout the encoder consumes.  Replaces four full passes over the 103 MB feature
 // map (BatchNorm, ReLU, pad + max-pool, movedim + reshape copy) by one read of it and a 26 MB write.  One workgroup =
-// one output row (b, oh) of 64 channels: its three input rows go through LDS ([c][3][W + 1]: reads along w are
-// coalesced, the pooled outputs leave c-contiguous).  Out-of-range window cells are skipped: after the ReLU every value
-// is >= 0, so this equals the reference's zero padding.
+// one output row (b, oh) of 64 channels.  Reading runs along w (lane = ow: a wave's nine window taps are nine
+// stride-2 spans of one input row, served by the caches), writing along c: the 64 x OW results turn through a small
+// LDS tile (pitch 65: conflict-free both ways) and leave as whole 256-byte token rows.  Out-of-range window cells
+// are skipped: after the ReLU every value is >= 0, so this equals the reference's zero padding.
 // =====================================================================================================
 __global__ __launch_bounds__(256) void bn_relu_pool_nhwc_kernel(const float *__restrict__ x,
                                                                 const float *__restrict__ scale,
                                                                 const float *__restrict__ shift, float *__restrict__ y,
                                                                 int C, int H, int W, int OH, int OW, int pad_top,
                                                                 int pad_left) {
-    extern __shared__ float pool_rows[];  // [64][3][W + 1]
+    __shared__ float tile[64 * 65];  // [ow within the 64-wide chunk][c]
     const int b = blockIdx.z, oh = blockIdx.x, c0 = blockIdx.y * 64;
-    const int pitch = W + 1, cpitch = 3 * pitch;
-    const int ih0 = 2 * oh - pad_top;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nc = C - c0 < 64 ? C - c0 : 64;
-    // ---- load 3 rows x nc channels x W, BatchNorm + ReLU on the way in (rows outside the image: zeros)
-    const int per_row = W;
-    for (int idx = threadIdx.x; idx < nc * 3 * per_row; idx += 256) {
-        const int w = idx % per_row;
-        const int r = (idx / per_row) % 3;
-        const int c = idx / (3 * per_row);
-        const int ih = ih0 + r;
-        float v = 0.f;
-        if (ih >= 0 && ih < H) {
-            v = x[(((int64_t)b * C + c0 + c) * H + ih) * W + w];
-            v = fmaxf(v * scale[c0 + c] + shift[c0 + c], 0.f);
-        }
-        pool_rows[c * cpitch + r * pitch + w] = v;
-    }
-    __syncthreads();
-    // ---- pooled outputs: thread -> (channel fastest, then ow)
-    for (int idx = threadIdx.x; idx < nc * OW; idx += 256) {
-        const int c = idx % nc, ow = idx / nc;
+    const int ih0 = 2 * oh - pad_top;
+    for (int ow0 = 0; ow0 < OW; ow0 += 64) {
+        const int ow = ow0 + lane;
         const int iw0 = 2 * ow - pad_left;
-        float m = 0.f;
+        if (ow < OW) {
+            for (int c = wave; c < nc; c += 4) {
+                const float sc = scale[c0 + c], sh = shift[c0 + c];
+                const float *xc = x + ((int64_t)b * C + c0 + c) * H * W;
+                float m = 0.f;
 #pragma unroll
-        for (int r = 0; r < 3; ++r)
+                for (int r = 0; r < 3; ++r) {
+                    const int ih = ih0 + r;
+                    if (ih < 0 || ih >= H) continue;
+                    const float *xr = xc + (int64_t)ih * W;
 #pragma unroll
-            for (int dx = 0; dx < 3; ++dx) {
-                const int iw = iw0 + dx;
-                if (iw >= 0 && iw < W) m = fmaxf(m, pool_rows[c * cpitch + r * pitch + iw]);
+                    for (int dx = 0; dx < 3; ++dx) {
+                        const int iw = iw0 + dx;
+                        if (iw >= 0 && iw < W) m = fmaxf(m, fmaf(xr[iw], sc, sh));
+                    }
+                }
+                tile[lane * 65 + c] = m;
             }
-        y[((int64_t)b * OH * OW + (int64_t)oh * OW + ow) * C + c0 + c] = m;
+        }
+        __syncthreads();
+        const int now = OW - ow0 < 64 ? OW - ow0 : 64;
+        for (int idx = threadIdx.x; idx < now * 64; idx += 256) {
+            const int o = idx >> 6, c = idx & 63;
+            if (c < nc) y[((int64_t)b * OH * OW + (int64_t)oh * OW + ow0 + o) * C + c0 + c] = tile[o * 65 + c];
+        }
+        __syncthreads();
     }
 }
 
@@ -798,12 +800,11 @@ int bn_relu_pool_nhwc_launch(const float *x, const float *scale, const float *sh
                              int pad_top, int pad_left, hipStream_t s) {
     if (!x || !scale || !shift || !y) return PIO_E_ARG;
     if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || pad_top < 0 || pad_top > 1 || pad_left < 0 || pad_left > 1) return PIO_E_SHAPE;
-    const size_t lds = (size_t)64 * 3 * (W + 1) * 4;
-    if (lds > 160 * 1024 || B > 65535) return PIO_E_SHAPE;
+    if (B > 65535 || (C + 63) / 64 > 65535) return PIO_E_SHAPE;
     const int OH = (H + 1) / 2, OW = (W + 1) / 2;
     ProfScope prof(PROF_LAYERNORM, 0.0, 4.0 * B * C * ((double)H * W + (double)OH * OW), s);
-    hipLaunchKernelGGL(bn_relu_pool_nhwc_kernel, dim3((unsigned)OH, (unsigned)((C + 63) / 64), (unsigned)B), dim3(256),
-                       lds, s, x, scale, shift, y, C, H, W, OH, OW, pad_top, pad_left);
+    hipLaunchKernelGGL(bn_relu_pool_nhwc_kernel, dim3((unsigned)OH, (unsigned)((C + 63) / 64), (unsigned)B), dim3(256), 0,
+                       s, x, scale, shift, y, C, H, W, OH, OW, pad_top, pad_left);
     return launch_status();
 }
 

@@ -138,7 +138,7 @@ class Conv2DDownsample(nn.Module):
     def forward_tokens(self, inputs: torch.Tensor):
         """The same network with its LAST layer's BatchNorm -> ReLU -> max-pool -> channels-last reshape done by ONE
         HIP kernel (pio_bn_relu_maxpool_tokens): returns the token array [B, OH*OW, C] directly, or None when this
-        configuration is not covered (CPU tensor, training-mode BatchNorm, maps wider than 212)."""
+        configuration is not covered (CPU tensor, training-mode BatchNorm)."""
         if not inputs.is_cuda or inputs.dim() != 4 or (self.norms is not None and self.training):
             return None
         from . import _lib as L
@@ -153,8 +153,6 @@ class Conv2DDownsample(nn.Module):
                 x = F.max_pool2d(F.pad(F.relu(x), same_padding(x.shape[1:], 3, 2)), kernel_size=3, stride=2)
         x = x.float().contiguous()
         b, c, h, w = x.shape
-        if w > 212:
-            return None
         if self.norms is not None:
             bn = self.norms[last]
             scale = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).float()
