@@ -176,3 +176,39 @@ def test_flow_mixed_precision_flag_is_honoured():
     assert M.FlowPerceiver(**kw).precision_policy == M.DEFAULT_POLICY["FlowPerceiver"]
     assert M.FlowPerceiver(mixed_precision=True, **kw).precision_policy == "fp16"   # autocast(fp16) analogue
     assert M.FlowPerceiver(mixed_precision=True, precision_policy="fp16x2w", **kw).precision_policy == "fp16x2w"
+
+
+def test_asm_hazard_checker_flags_copies_behind_inline_asm(tmp_path):
+    import os
+    """tools/check_asm_hazards.py (run by the csrc Makefile over the inline-assembly attention kernels): a register copy
+    between an inline-asm LDS read and its wait, or right behind an inline-asm MFMA, is a finding; the same code with
+    the wait / enough distance is clean; findings do not leak across basic blocks."""
+    import subprocess
+    import sys
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    tool = os.path.join(root, "tools", "check_asm_hazards.py")
+
+    def run(body):
+        f = tmp_path / "k.s"
+        f.write_text("_ZN3pio4testEv:\n" + body + "\ts_endpgm\n")
+        r = subprocess.run([sys.executable, tool, str(f), "test"], capture_output=True, text=True)
+        return r.returncode, r.stdout
+
+    asm = lambda s: "\t;;#ASMSTART\n\t" + s + "\n\t;;#ASMEND\n"  # noqa: E731
+    rc, out = run(asm("ds_read_b128 v[4:7], v1 offset:0") + "\tv_mov_b32_e32 v9, v5\n" + asm("s_waitcnt lgkmcnt(0)"))
+    assert rc == 1 and "LDS read" in out
+    rc, out = run(asm("ds_read_b128 v[4:7], v1 offset:0") + asm("s_waitcnt lgkmcnt(0)") + "\tv_mov_b32_e32 v9, v5\n")
+    assert rc == 0, out
+    rc, out = run(asm("ds_read_b128 v[4:7], v1 offset:0") + asm("ds_read_b128 v[8:11], v1 offset:64") +
+                  asm("s_waitcnt lgkmcnt(1)") + "\tv_mov_b32_e32 v20, v5\n")
+    assert rc == 0, out                       # in-order returns: one read may stay in flight
+    rc, out = run(asm("ds_read_b128 v[4:7], v1 offset:0") + asm("ds_read_b128 v[8:11], v1 offset:64") +
+                  asm("s_waitcnt lgkmcnt(1)") + "\tv_mov_b32_e32 v20, v9\n")
+    assert rc == 1                            # ... but not the one that is read
+    rc, out = run(asm("v_mfma_f32_32x32x16_f16 a[0:15], v[2:5], v[6:9], a[0:15]") + "\tv_accvgpr_read_b32 v30, a3\n")
+    assert rc == 1 and "MFMA" in out
+    rc, out = run(asm("v_mfma_f32_32x32x16_f16 a[0:15], v[2:5], v[6:9], a[0:15]") +
+                  asm("s_nop 15\n\ts_nop 15\n\ts_nop 15") + "\tv_accvgpr_read_b32 v30, a3\n")
+    assert rc == 0, out
+    rc, out = run(asm("ds_read_b128 v[4:7], v1 offset:0") + "\ts_cbranch_scc1 .LBB0_2\n.LBB0_2:\n\tv_mov_b32_e32 v9, v5\n")
+    assert rc == 0, out                       # per basic block only
