@@ -13,7 +13,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int ITER = 2000;
 
 // KIND: 0 v_pk_fma_f32, 1 v_exp_f32, 2 v_fma_f32, 3 v_max3_f32, 4 v_cvt_pk_f16_f32, 5 v_pk_add_f32, 6 v_pk_mul_f32,
-// 7 v_add_f32, 8 v_mov_b32, 9 v_fma_f32 with an SGPR-free literal-free form reading three different registers
+// 7 v_add_f32, 8 v_mov_b32, 9 v_dot2_f32_f16, 10 v_pk_add_f16, 11 v_fma_mix_f32
 template <int KIND>
 __device__ __forceinline__ void valu(f32x2 &x, const f32x2 &c1, const f32x2 &c2) {
     if constexpr (KIND == 0) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(x) : "v"(c1), "v"(c2));
@@ -25,6 +25,9 @@ __device__ __forceinline__ void valu(f32x2 &x, const f32x2 &c1, const f32x2 &c2)
     else if constexpr (KIND == 6) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(x) : "v"(c1));
     else if constexpr (KIND == 7) asm volatile("v_add_f32 %0, %0, %1" : "+v"(x[0]) : "v"(c2[0]));
     else if constexpr (KIND == 8) asm volatile("v_mov_b32 %0, %1" : "+v"(x[0]) : "v"(c2[0]));
+    else if constexpr (KIND == 9) asm volatile("v_dot2_f32_f16 %0, %1, %2, %0" : "+v"(x[0]) : "v"(c1[0]), "v"(c2[0]));
+    else if constexpr (KIND == 10) asm volatile("v_pk_add_f16 %0, %0, %1" : "+v"(x[0]) : "v"(c2[0]));
+    else if constexpr (KIND == 11) asm volatile("v_fma_mix_f32 %0, %1, 1.0, %0 op_sel_hi:[1,0,0]" : "+v"(x[0]) : "v"(c2[0]));
 }
 
 // MODE bit 0: this wave issues MFMAs; bit 1: it issues VALU work; KIND 0 = packed FMA, 1 = v_exp_f32
@@ -130,6 +133,9 @@ int main() {
     TRIO(6, "v_pk_mul_f32")
     TRIO(7, "v_add_f32")
     TRIO(8, "v_mov_b32")
+    TRIO(9, "v_dot2_f32_f16")
+    TRIO(10, "v_pk_add_f16")
+    TRIO(11, "v_fma_mix_f32")
     run<16, 64, 0>("2 waves/SIMD: both 16 MFMA only", 512, 1, 1, out, cyc);
     run<16, 64, 2>("2 waves/SIMD: both interleave 16 MFMA with 64 v_fma_f32", 512, 3, 3, out, cyc);
     run<16, 64, 2>("2 waves/SIMD: both 64 v_fma_f32 only", 512, 2, 2, out, cyc);
