@@ -56,6 +56,11 @@ static __device__ __attribute__((aligned(16))) uint32_t g_zero_w[4] = {0, 0, 0, 
 // last one executed survives) and, around the kernel, s_memtime / s_memrealtime (the clock held under load).
 __device__ unsigned long long g_wstamps[8];
 __device__ unsigned long long g_wclk[4];
+__device__ unsigned long long g_westamps[16];  // staged producer epilogue: start, after the barrier, after each row block
+#define PIO_WESTAMP(i)                                                                          \
+    do {                                                                                        \
+        if (blockIdx.x == 0 && threadIdx.x == 0) g_westamps[i] = __builtin_readcyclecounter();  \
+    } while (0)
 #ifndef PIO_WIDE_ABL
 #define PIO_WIDE_ABL 0  // timing-only ablations, compile time: bit 0 = no LDS fragment reads, 1 = no DMA pieces, 2 = no barrier
 #endif
@@ -70,6 +75,7 @@ __device__ unsigned long long g_wclk[4];
 #endif
 #else
 #define PIO_WSTAMP(i)
+#define PIO_WESTAMP(i)
 #endif
 
 template <int I, int N, class F>
@@ -406,8 +412,10 @@ __global__ __launch_bounds__(256) void gemm_nt_wide(const GemmParams p, int tile
             // 4 rows x 256 contiguous bytes (whole 128-byte lines) instead of 16 rows x 64 bytes (half lines, each line
             // written by two instructions): the direct epilogue below moves its 128 MB per launch at 4.4 TB/s.
             if (!p.C && p.X16_lo && p.staged_epi && interior && j == ntl - 1) {
+                PIO_WESTAMP(0);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();  // every wave has read its last fragments out of the ring
+                PIO_WESTAMP(1);
                 constexpr int ROWP = 132;      // floats per staged row: 128 + 4 (conflict-free b128 writes and reads)
                 float *const stg = (float *)(smem + wave * 32768);
                 const int cr = lane >> 4, cc = (lane & 15) * 8;
@@ -543,7 +551,12 @@ __global__ __launch_bounds__(256) void gemm_nt_wide(const GemmParams p, int tile
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
+                    PIO_WESTAMP(2 + mi);
                 }
+#ifdef PIO_GEMM_STAMPS
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (dev build: the last stamp includes the stores' completion)
+#endif
+                PIO_WESTAMP(10);
                 continue;
             }
         }
@@ -789,6 +802,9 @@ __global__ __launch_bounds__(256) void gemm_nt_wide(const GemmParams p, int tile
 
 #ifdef PIO_GEMM_STAMPS
 extern "C" int pio_debug_wide_mode(void) { return PIO_WIDE_ABL; }
+extern "C" int pio_debug_wide_epi_stamps(unsigned long long *out16) {
+    return hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_westamps), sizeof(g_westamps)) == hipSuccess ? 0 : 1;
+}
 extern "C" int pio_debug_wide_stamps(unsigned long long *out12) {
     if (hipMemcpyFromSymbol(out12, HIP_SYMBOL(g_wstamps), sizeof(g_wstamps)) != hipSuccess) return 1;
     return hipMemcpyFromSymbol(out12 + 8, HIP_SYMBOL(g_wclk), sizeof(g_wclk)) == hipSuccess ? 0 : 1;
