@@ -114,13 +114,34 @@ __device__ __forceinline__ void mfma_first(f32x4 &c, typename Op<DT>::V8 a, type
     else asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(c) : "v"(a), "v"(b));
 }
 
+// The same with the 32x32x16 MFMA (MF == 1 below): an MFMA twice as long hides the issue stall of an LDS-DMA piece twice
+// as well -- tools/microbench/dma_issue.hip: 8 pieces beside 64 MFMAs 16x16x32 cost 312 cycles per 1024, beside 32
+// MFMAs 32x32x16 133.
+template <int DT>
+__device__ __forceinline__ void mfma_acc32(f32x16 &c, typename Op<DT>::V8 a, typename Op<DT>::V8 b) {
+    if constexpr (DT == PIO_DT_F16) asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+    else asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+template <int DT>
+__device__ __forceinline__ void mfma_first32(f32x16 &c, typename Op<DT>::V8 a, typename Op<DT>::V8 b) {
+    if constexpr (DT == PIO_DT_F16) asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=a"(c) : "v"(a), "v"(b));
+    else asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=a"(c) : "v"(a), "v"(b));
+}
+
 // OUT: 0 = 16-bit C, 2 = fp32 C; RES: 0 = no residual, 1 = fp32 residual R, 2 = residual as a 16-bit pair
 // R16_hi + R16_lo (LNF == 1 only; the result then leaves as the pair X16 / X16_lo, and as fp32 only if C is given).
 // LNF, the LayerNorm fold (pio_gemm_t): 1 = producer (OUT == 2): also stores a 16-bit copy of the result and per-row
 // partial (sum, sum of squares) per 128-column block; 2 = consumer (OUT == 0, K == 1024): the result is
 // rstd_m * acc - rstd_m * mean_m * c[n] + bias[n], with mean / rstd of row m of A from the producer's partial sums.
-template <int DT, int ACT, int OUT, int RES, int LNF>
+// MF: 0 = MFMA 16x16x32 (every variant, any shape), 1 = MFMA 32x32x16 (the LayerNorm fold's consumer and its staged
+// producer on problems of whole 256 x 256 tiles: the launcher decides).  Same LDS layout, DMA and phase structure; a
+// wave's 128 x 128 quarter is 4 x 4 blocks of 32 x 32, a fragment = 32 rows x 16 k (row lane & 31, 16-byte chunk
+// 2 s + (lane >> 5) of the 64-byte row: conflict-free with the same swizzle -- ds_read_b128's lane groups hold rows that
+// are distinct mod 16), the B rows of a 32-column group permuted so that a lane (row lane & 31, half lane >> 5) holds
+// 16 CONSECUTIVE output columns 16 (lane >> 5) + e of the block in its 16 accumulator registers.
+template <int DT, int ACT, int OUT, int RES, int LNF, int MF = 0>
 __global__ __launch_bounds__(256) void gemm_nt_wide(const GemmParams p, int tiles_m, int tiles_n) {
+    static_assert(MF == 0 || (OUT == 0 && LNF == 2) || (OUT == 2 && RES == 2 && LNF == 1), "MF == 1: fold variants only");
     typedef typename Op<DT>::T T;
     typedef typename Op<DT>::V8 V8;
     __shared__ __attribute__((aligned(16))) char smem[W_SMEM];
@@ -247,7 +268,21 @@ __global__ __launch_bounds__(256) void gemm_nt_wide(const GemmParams p, int tile
     const int fb1 = (8 * (fr >> 2) + 4 + (fr & 3)) * 64 + ((fq ^ fsw(2 * (fr >> 2) + 1)) << 4);
     const int a_base = wm * 128 * 64, b_base = W_AB + wn * 128 * 64;
     V8 af[2][8], bf[2][8];
-    f32x4 acc[8][8];
+    using AccT = std::conditional_t<MF == 1, f32x16, f32x4>;
+    AccT acc[MF ? 4 : 8][MF ? 4 : 8];
+    // MF == 1: fragment j = 2 * block + s (k-step s of the 32-deep slice)
+    const int r31 = lane & 31, hq = lane >> 5;
+    const int pi31 = (r31 & 3) + 4 * (r31 >> 3) + 16 * ((r31 >> 2) & 1);  // B row of MFMA row index r31
+    const int fa32_0 = r31 * 64 + (((0 + hq) ^ fsw(r31 >> 2)) << 4), fa32_1 = r31 * 64 + (((2 + hq) ^ fsw(r31 >> 2)) << 4);
+    const int fb32_0 = pi31 * 64 + (((0 + hq) ^ fsw(pi31 >> 2)) << 4), fb32_1 = pi31 * 64 + (((2 + hq) ^ fsw(pi31 >> 2)) << 4);
+    auto a_frag = [&](const char *st, int j) __attribute__((always_inline)) {
+        if constexpr (MF == 1) return *(const V8 *)(st + a_base + (j >> 1) * 2048 + ((j & 1) ? fa32_1 : fa32_0));
+        else return *(const V8 *)(st + a_base + j * 1024 + fa);
+    };
+    auto b_frag = [&](const char *st, int j) __attribute__((always_inline)) {
+        if constexpr (MF == 1) return *(const V8 *)(st + b_base + (j >> 1) * 2048 + ((j & 1) ? fb32_1 : fb32_0));
+        else return *(const V8 *)(st + b_base + (j >> 1) * 2048 + ((j & 1) ? fb1 : fb0));
+    };
 
     // ---- prologue: slices 0..3 in flight, slice 0 landed and in fragment set 0
     dma_tile(0);
@@ -262,8 +297,8 @@ __global__ __launch_bounds__(256) void gemm_nt_wide(const GemmParams p, int tile
     __builtin_amdgcn_s_barrier();
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        af[0][i] = *(const V8 *)(smem + a_base + i * 1024 + fa);
-        bf[0][i] = *(const V8 *)(smem + b_base + (i >> 1) * 2048 + ((i & 1) ? fb1 : fb0));
+        af[0][i] = a_frag(smem, i);
+        bf[0][i] = b_frag(smem, i);
     }
 
     int rslot = 1;      // ring slot of the slice whose fragments the next phase reads
@@ -307,6 +342,21 @@ __global__ __launch_bounds__(256) void gemm_nt_wide(const GemmParams p, int tile
             // waves' pieces 16 cycles apart (tile loop compiled once per wave index) changed nothing, and a branch on
             // the wave index between MFMAs costs far more than it saves.
             constexpr int PIECE = (g >= 2 && !skip_dma) ? (g == 15 ? 7 : ((g & 1) == 0 ? (g - 2) >> 1 : -1)) : -1;
+            if constexpr (MF == 1) {
+                // 32 MFMAs 32x32x16: groups 0..7 run k-step 0 of the 16 blocks, groups 8..15 k-step 1
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    constexpr int ks = g >> 3;
+                    const int blk = (2 * g + t) & 15, mi = blk >> 2, ni = blk & 3;
+                    if constexpr (FIRST && ks == 0) mfma_first32<DT>(acc[mi][ni], bf[P][2 * ni + ks], af[P][2 * mi + ks]);
+                    else mfma_acc32<DT>(acc[mi][ni], bf[P][2 * ni + ks], af[P][2 * mi + ks]);
+                    if (PIECE >= 0 && t == 1) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        piece(PIECE >= 0 ? PIECE : 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            } else {
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const int mi = (4 * g + t) >> 3, ni = (4 * g + t) & 7;
@@ -317,6 +367,7 @@ __global__ __launch_bounds__(256) void gemm_nt_wide(const GemmParams p, int tile
                     piece(PIECE >= 0 ? PIECE : 0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
+            }
             }
             __builtin_amdgcn_sched_barrier(0);  // (reads placed BEFORE the group's MFMAs would be waited for by them)
             if constexpr (g == 0) issue_begin();
@@ -341,11 +392,11 @@ __global__ __launch_bounds__(256) void gemm_nt_wide(const GemmParams p, int tile
                 PIO_WSTAMP(4);
             }
             if constexpr (g >= 2 && g < 6 && !skip_rd) {
-                af[P ^ 1][2 * (g - 2)] = *(const V8 *)(rb + a_base + (2 * (g - 2)) * 1024 + fa);
-                af[P ^ 1][2 * (g - 2) + 1] = *(const V8 *)(rb + a_base + (2 * (g - 2) + 1) * 1024 + fa);
+                af[P ^ 1][2 * (g - 2)] = a_frag(rb, 2 * (g - 2));
+                af[P ^ 1][2 * (g - 2) + 1] = a_frag(rb, 2 * (g - 2) + 1);
             } else if constexpr (g >= 6 && g < 10 && !skip_rd) {
-                bf[P ^ 1][2 * (g - 6)] = *(const V8 *)(rb + b_base + (g - 6) * 2048 + fb0);
-                bf[P ^ 1][2 * (g - 6) + 1] = *(const V8 *)(rb + b_base + (g - 6) * 2048 + fb1);
+                bf[P ^ 1][2 * (g - 6)] = b_frag(rb, 2 * (g - 6));
+                bf[P ^ 1][2 * (g - 6) + 1] = b_frag(rb, 2 * (g - 6) + 1);
             }
             if constexpr (g == 15) {
                 issue_end();
@@ -378,7 +429,16 @@ __global__ __launch_bounds__(256) void gemm_nt_wide(const GemmParams p, int tile
         //  epilogue -- they ride through the main loop in 32 of the ~100 free VGPRs instead of exposing their latency)
         constexpr int NDMA0 = LNF == 2 ? 10 : 1;
         f32x4 part[8];
-        if constexpr (LNF == 2) {
+        if constexpr (LNF == 2 && MF == 1) {
+            // (row 32 mi + (lane & 31): the (sum, sum of squares) of column blocks 4 (lane >> 5) .. + 3 -- two loads)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                const int m = o_m - fr + 32 * mi + r31;
+                const float *src = p.ln_part + ((int64_t)m * 8 + 4 * hq) * 2;
+                part[2 * mi] = *(const f32x4 *)src;
+                part[2 * mi + 1] = *(const f32x4 *)(src + 4);
+            }
+        } else if constexpr (LNF == 2) {
 #pragma unroll
             for (int mi = 0; mi < 8; ++mi) {
                 int m = o_m + mi * 16;
@@ -411,7 +471,7 @@ __global__ __launch_bounds__(256) void gemm_nt_wide(const GemmParams p, int tile
             // lane >> 4, eight consecutive columns (lane & 15) * 8).  Every residual load and every store then covers
             // 4 rows x 256 contiguous bytes (whole 128-byte lines) instead of 16 rows x 64 bytes (half lines, each line
             // written by two instructions): the direct epilogue below moves its 128 MB per launch at 4.4 TB/s.
-            if (!p.C && p.X16_lo && p.staged_epi && interior && j == ntl - 1) {
+            if (MF == 1 || (!p.C && p.X16_lo && p.staged_epi && interior && j == ntl - 1)) {  // (MF == 1: launcher)
                 PIO_WESTAMP(0);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();  // every wave has read its last fragments out of the ring
@@ -446,6 +506,21 @@ __global__ __launch_bounds__(256) void gemm_nt_wide(const GemmParams p, int tile
                 for (int mi = 0; mi < 8; ++mi) {
                     if (mi + RD < 8) r_load((mi + RD) % (RD + 1), mi + RD);
                     // accumulators of row block mi -> LDS, accumulator arrangement (row fr, 8 columns at 32 pp + 8 fq)
+                    if constexpr (MF == 1) {
+                        // (32-row blocks: every other 16-row step writes rows 32 (mi / 2) + (lane & 31), 16 columns at
+                        //  32 ni + 16 (lane >> 5); the staging rows hold 32 rows then)
+                        if ((mi & 1) == 0) {
+#pragma unroll
+                            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                                for (int e4 = 0; e4 < 4; ++e4) {
+                                    f32x4 x;
+#pragma unroll
+                                    for (int r = 0; r < 4; ++r) x[r] = acc_read(acc[mi >> 1][ni][4 * e4 + r]);
+                                    *(f32x4 *)(stg + r31 * ROWP + 32 * ni + 16 * hq + 4 * e4) = x;
+                                }
+                        }
+                    } else {
 #pragma unroll
                     for (int pp = 0; pp < 4; ++pp) {
                         f32x4 x0, x1;
@@ -457,12 +532,14 @@ __global__ __launch_bounds__(256) void gemm_nt_wide(const GemmParams p, int tile
                         *(f32x4 *)(stg + fr * ROWP + 32 * pp + 8 * fq) = x0;
                         *(f32x4 *)(stg + fr * ROWP + 32 * pp + 8 * fq + 4) = x1;
                     }
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                     // ... and back, row-coalesced: 4 steps of 4 rows (LDS operations of one wave execute in order)
 #pragma unroll
                     for (int st = 0; st < 4; ++st) {
-                        const f32x4 a0 = *(const f32x4 *)(stg + (st * 4 + cr) * ROWP + cc);
-                        const f32x4 a1 = *(const f32x4 *)(stg + (st * 4 + cr) * ROWP + cc + 4);
+                        const int srow = (MF == 1 ? (mi & 1) * 16 : 0) + st * 4 + cr;
+                        const f32x4 a0 = *(const f32x4 *)(stg + srow * ROWP + cc);
+                        const f32x4 a1 = *(const f32x4 *)(stg + srow * ROWP + cc + 4);
                         const V8 hh = rh[mi % (RD + 1)][st], ll = rl[mi % (RD + 1)][st];
                         f32x4 x0, x1;
                         float rsum, rsq;
@@ -560,7 +637,9 @@ __global__ __launch_bounds__(256) void gemm_nt_wide(const GemmParams p, int tile
                 continue;
             }
         }
-        if constexpr (OUT == 2) {
+        if constexpr (OUT == 2 && MF == 1) {
+            // (every tile of an MF == 1 producer leaves through the staged epilogue above)
+        } else if constexpr (OUT == 2) {
             // fp32 out [+ residual]: 64 stores of 4 columns; the residual of row block mi+1 is loaded while block mi
             // is converted and stored
             float *const cf = (float *)p.C;
@@ -674,6 +753,64 @@ __global__ __launch_bounds__(256) void gemm_nt_wide(const GemmParams p, int tile
                         dstp[1] = rsq;
                     }
                     __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        } else if constexpr (MF == 1) {
+            // ---- LayerNorm fold's consumer, 32 x 32 blocks, whole tiles only (launcher): lane = row 32 mi + (lane & 31),
+            // 16 consecutive columns 32 ni + 16 (lane >> 5) + e per block: two 16-byte stores per block
+            T *const cbase = (T *)p.C;
+            float rs[4], nmr[4];
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                float sm = part[2 * mi][0] + part[2 * mi][2] + part[2 * mi + 1][0] + part[2 * mi + 1][2];
+                float sq = part[2 * mi][1] + part[2 * mi][3] + part[2 * mi + 1][1] + part[2 * mi + 1][3];
+                sm += __shfl_xor(sm, 32);
+                sq += __shfl_xor(sq, 32);
+                const float mean = sm * (1.0f / 1024.0f);
+                float var = sq * (1.0f / 1024.0f) - mean * mean;
+                var = var > 0.f ? var : 0.f;
+                rs[mi] = 1.0f / sqrtf(var + p.ln_eps);
+                nmr[mi] = -mean * rs[mi];
+            }
+            auto val4m = [&](f32x4 a, f32x4 b, f32x4 c, int mi) {
+                f32x4 x;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) x[r] = a[r] * rs[mi] + (nmr[mi] * c[r] + b[r]);
+                if constexpr (ACT == 1) {
+                    const pio_f32x2 lo = gelu_erf2(pio_f32x2{x[0], x[1]}), hi = gelu_erf2(pio_f32x2{x[2], x[3]});
+                    x = f32x4{lo[0], lo[1], hi[0], hi[1]};
+                }
+                return x;
+            };
+            const int m0 = o_m - fr + r31;
+            const int n0 = o_n0 + 16 * hq;
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                f32x4 b4[4], c4[4];
+#pragma unroll
+                for (int e4 = 0; e4 < 4; ++e4) {
+                    b4[e4] = *(const f32x4 *)(bstash + 32 * ni + 16 * hq + 4 * e4);
+                    c4[e4] = *(const f32x4 *)(cstash + 32 * ni + 16 * hq + 4 * e4);
+                }
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) {
+                    V8 h0, h1;
+#pragma unroll
+                    for (int e4 = 0; e4 < 4; ++e4) {
+                        f32x4 a;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) a[r] = acc_read(acc[mi][ni][4 * e4 + r]);
+                        const f32x4 y = val4m(a, b4[e4], c4[e4], mi);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            if (e4 < 2) h0[4 * e4 + r] = Op<DT>::from_f32(y[r]);
+                            else h1[4 * (e4 - 2) + r] = Op<DT>::from_f32(y[r]);
+                        }
+                    }
+                    T *dst = cbase + (int64_t)(m0 + 32 * mi) * p.ldc + n0 + 32 * ni;
+                    *(V8 *)dst = h0;
+                    *(V8 *)(dst + 8) = h1;
+                    __builtin_amdgcn_sched_barrier(0);  // (else all 256 accumulators are read out before the first store)
                 }
             }
         } else {
@@ -854,9 +991,27 @@ void gemm_wide_launch(const GemmParams &p, int dtype, hipStream_t s) {
     dim3 grid((unsigned)G, 1, 1), block(256, 1, 1);
 #define PIO_WK(DTV, ACT, OUT, R, LNF) \
     hipLaunchKernelGGL((gemm_nt_wide<DTV, ACT, OUT, R, LNF>), grid, block, 0, s, p, tiles_m, tiles_n)
+    // MFMA 32x32x16 variants: the LayerNorm fold's consumer and its staged producer on whole tiles (one tile per
+    // workgroup for the producer: its staged epilogue is the last tile's).  An experiment, off unless PIO_WIDE_MF32=1:
+    // the main loop needs 7 % fewer cycles (the longer MFMA hides the LDS-DMA issue stalls better) and the chip answers
+    // with a 5 % lower clock -- 74 956 cycles at 1.45 GHz against 78 304 at 1.53 GHz for a producer launch back to back,
+    // 112 against 107 us for q|k|v in the model: the path is power-limited, not issue-limited.
+    static const bool mf32_on = [] {
+        const char *e = getenv("PIO_WIDE_MF32");
+        return e && atoi(e) != 0;
+    }();
+    const bool whole = (p.M % W_BM) == 0 && (p.N % W_BN) == 0 && p.n_store == p.N;
+    const bool mf_cons = mf32_on && whole && p.ln_part && !p.out_f32;
+    const bool mf_prod = mf32_on && whole && p.row_part && p.R16_hi && !p.C && p.X16_lo && p.staged_epi &&
+                         (int64_t)tiles_m * tiles_n <= G;
+#define PIO_WKM(DTV, ACT, OUT, R, LNF) \
+    hipLaunchKernelGGL((gemm_nt_wide<DTV, ACT, OUT, R, LNF, 1>), grid, block, 0, s, p, tiles_m, tiles_n)
 #define PIO_WS(DTV)                                                  \
     do {                                                             \
-        if (p.row_part && p.R16_hi) PIO_WK(DTV, 0, 2, 2, 1);         \
+        if (mf_prod) PIO_WKM(DTV, 0, 2, 2, 1);                       \
+        else if (mf_cons && p.act == 1) PIO_WKM(DTV, 1, 0, 0, 2);    \
+        else if (mf_cons) PIO_WKM(DTV, 0, 0, 0, 2);                  \
+        else if (p.row_part && p.R16_hi) PIO_WK(DTV, 0, 2, 2, 1);    \
         else if (p.row_part) PIO_WK(DTV, 0, 2, 1, 1);                \
         else if (p.out_f32 && p.R) PIO_WK(DTV, 0, 2, 1, 0);          \
         else if (p.out_f32) PIO_WK(DTV, 0, 2, 0, 0);                 \
@@ -869,6 +1024,7 @@ void gemm_wide_launch(const GemmParams &p, int dtype, hipStream_t s) {
     else PIO_WS(PIO_DT_BF16);
 #undef PIO_WS
 #undef PIO_WK
+#undef PIO_WKM
 }
 
 }  // namespace pio

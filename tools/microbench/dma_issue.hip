@@ -14,7 +14,7 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int ITER = 1000;
 
-template <int NP, int MODE>
+template <int NP, int MODE, bool BIG = false>
 __global__ __launch_bounds__(256) void k(const char *src, float *out, unsigned long long *cyc) {
     __shared__ __attribute__((aligned(16))) char lds[64 * 1024];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -25,6 +25,10 @@ __global__ __launch_bounds__(256) void k(const char *src, float *out, unsigned l
     }
     f32x4 acc[16];
     for (int k2 = 0; k2 < 16; ++k2) acc[k2] = f32x4{0.f, 0.f, 0.f, 0.f};
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    f32x16 accb[4];
+    for (int k2 = 0; k2 < 4; ++k2)
+        for (int e = 0; e < 16; ++e) accb[k2][e] = 0.f;
     // per-lane source offset: 16 rows x 64 B of a 2 KiB-pitch matrix (the GEMM pattern)
     uint32_t off = (uint32_t)((lane >> 2) * 2048 + (lane & 3) * 16);
     const char *base = src + (blockIdx.x & 63) * 65536 + wave * 16384;
@@ -36,7 +40,11 @@ __global__ __launch_bounds__(256) void k(const char *src, float *out, unsigned l
     for (int it = 0; it < ITER; ++it) {
 #pragma unroll
         for (int m = 0; m < 64; ++m) {
-            asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[m & 15]) : "v"(a), "v"(b));
+            if (BIG) {
+                if ((m & 1) == 0) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(accb[(m >> 1) & 3]) : "v"(a), "v"(b));
+            } else {
+                asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[m & 15]) : "v"(a), "v"(b));
+            }
             const bool here = MODE == 3 ? (m >= 8 && m < 8 + NP) : (MODE == 4 ? (m >= 8 && m < 8 + 2 * NP && (m & 1) == 0)
                                                                                  : (m % (64 / (NP > 0 ? NP : 1))) == 0);
             if (NP > 0 && here) {
@@ -63,16 +71,17 @@ __global__ __launch_bounds__(256) void k(const char *src, float *out, unsigned l
     __syncthreads();
     float s = 0.f;
     for (int k2 = 0; k2 < 16; ++k2) s += acc[k2][0] + acc[k2][3];
+    for (int k2 = 0; k2 < 4; ++k2) s += accb[k2][0] + accb[k2][15];
     s += (float)lds[threadIdx.x * 16];
     out[blockIdx.x * 256 + threadIdx.x] = s;
     if (lane == 0) cyc[blockIdx.x * 4 + wave] = t1 - t0;
 }
 
-template <int NP, int MODE>
+template <int NP, int MODE, bool BIG = false>
 static void run(const char *what, const char *src, float *out, unsigned long long *cyc) {
-    hipLaunchKernelGGL((k<NP, MODE>), dim3(256), dim3(256), 0, 0, src, out, cyc);
+    hipLaunchKernelGGL((k<NP, MODE, BIG>), dim3(256), dim3(256), 0, 0, src, out, cyc);
     hipDeviceSynchronize();
-    hipLaunchKernelGGL((k<NP, MODE>), dim3(256), dim3(256), 0, 0, src, out, cyc);
+    hipLaunchKernelGGL((k<NP, MODE, BIG>), dim3(256), dim3(256), 0, 0, src, out, cyc);
     hipDeviceSynchronize();
     unsigned long long h[4];
     hipMemcpy(h, cyc, sizeof(h), hipMemcpyDeviceToHost);
@@ -96,5 +105,11 @@ int main() {
     run<4, 0>("+ 4 global_load_lds_dwordx4, SGPR base + lane offset", src, out, cyc);
     run<8, 3>("+ 8 global_load_lds_dwordx4 behind 8 consecutive MFMAs", src, out, cyc);
     run<8, 4>("+ 8 global_load_lds_dwordx4 behind every other of 16 consecutive MFMAs", src, out, cyc);
+    printf("the same round as 32 MFMAs 32x32x16 (32 cycles each):\n");
+    run<0, 0, true>("MFMAs only", src, out, cyc);
+    run<4, 0, true>("+ 4 global_load_lds_dwordx4", src, out, cyc);
+    run<8, 0, true>("+ 8 global_load_lds_dwordx4", src, out, cyc);
+    run<16, 0, true>("+ 16 global_load_lds_dwordx4", src, out, cyc);
+    run<8, 3, true>("+ 8 global_load_lds_dwordx4 behind 8 consecutive slots", src, out, cyc);
     return 0;
 }
