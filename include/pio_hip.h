@@ -166,8 +166,9 @@ int pio_ln_fold_enable(int on);
 /* 0: automatic (default; env PIO_GEMM_TILE gives the initial value), 64: 64x64 tiles of the 128-tile kernel (automatic
  * for problems with fewer than 192 tiles of 128x128: small batches), 128: 128x128 tile, 256: 256x256 tile,
  * 1: persistent 256x128 streaming kernel wherever it is legal, 2: persistent 256x256 four-wave kernel wherever
- * it is legal, 3: the LayerNorm-fold producer on the two-workgroups-per-CU kernel (gemm_nt_duo).  Returns the
- * previous setting. */
+ * it is legal, 3: the LayerNorm-fold producer on the two-workgroups-per-CU kernel (gemm_nt_duo), 4: the LayerNorm-fold
+ * GEMMs on the MFMA 32x32x16 variants of the four-wave kernel (fewer cycles, lower clock: level).  Returns the previous
+ * setting. */
 int pio_gemm_kernel_override(int which);
 /* Variant of the fused self-attention kernel on its hot shape (128-wide heads, V row-major out of the fused q|k|v GEMM,
  * >= 256 queries): 0 = lock-step waves (default; env PIO_FLASH_VARIANT gives the initial value), 1 = one wave per SIMD

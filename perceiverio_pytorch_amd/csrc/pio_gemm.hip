@@ -307,6 +307,7 @@ int gemm_nt_launch(const pio_gemm_t &g, hipStream_t s) {
             return (e && atoi(e) == 0) ? 0 : 1;
         }();
         p.staged_epi = staged;
+        p.mf32 = gemm_kernel_choice() == 4 ? 1 : 0;
     }
     if (g.b_lo_n0 && (!g.B_lo || g.A_lo)) return PIO_E_ARG;
     p.n_store = g.n_store > g.N ? g.n_store : g.N;

@@ -992,7 +992,7 @@ void gemm_wide_launch(const GemmParams &p, int dtype, hipStream_t s) {
 #define PIO_WK(DTV, ACT, OUT, R, LNF) \
     hipLaunchKernelGGL((gemm_nt_wide<DTV, ACT, OUT, R, LNF>), grid, block, 0, s, p, tiles_m, tiles_n)
     // MFMA 32x32x16 variants: the LayerNorm fold's consumer and its staged producer on whole tiles (one tile per
-    // workgroup for the producer: its staged epilogue is the last tile's).  An experiment, off unless PIO_WIDE_MF32=1:
+    // workgroup for the producer: its staged epilogue is the last tile's).  An experiment, off unless PIO_WIDE_MF32=1 / pio_gemm_kernel_override(4):
     // the main loop needs 7 % fewer cycles (the longer MFMA hides the LDS-DMA issue stalls better) and the chip answers
     // with a 5 % lower clock -- 74 956 cycles at 1.45 GHz against 78 304 at 1.53 GHz for a producer launch back to back,
     // 112 against 107 us for q|k|v in the model: the path is power-limited, not issue-limited.
@@ -1001,8 +1001,9 @@ void gemm_wide_launch(const GemmParams &p, int dtype, hipStream_t s) {
         return e && atoi(e) != 0;
     }();
     const bool whole = (p.M % W_BM) == 0 && (p.N % W_BN) == 0 && p.n_store == p.N;
-    const bool mf_cons = mf32_on && whole && p.ln_part && !p.out_f32;
-    const bool mf_prod = mf32_on && whole && p.row_part && p.R16_hi && !p.C && p.X16_lo && p.staged_epi &&
+    const bool mf_any = mf32_on || p.mf32;
+    const bool mf_cons = mf_any && whole && p.ln_part && !p.out_f32;
+    const bool mf_prod = mf_any && whole && p.row_part && p.R16_hi && !p.C && p.X16_lo && p.staged_epi &&
                          (int64_t)tiles_m * tiles_n <= G;
 #define PIO_WKM(DTV, ACT, OUT, R, LNF) \
     hipLaunchKernelGGL((gemm_nt_wide<DTV, ACT, OUT, R, LNF, 1>), grid, block, 0, s, p, tiles_m, tiles_n)

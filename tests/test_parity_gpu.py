@@ -1185,3 +1185,28 @@ def test_self_attention_kernel_variants_agree(dev, variant, shape, policy):
     k = 1.0 if policy == "fp16" else 8.0       # bf16 P: 8 mantissa bits instead of 11
     assert ((y1 - y0).abs().max() / scale).item() <= 3e-4 * k, f"variant {variant} {shape}"
     assert ((y1 - y0).norm() / y0.norm()).item() <= 2e-4 * k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("policy", ["fp16", "fp16x2w"])
+def test_fold_gemms_on_32x32_mfma_agree(dev, policy):
+    """pio_gemm_kernel_override(4): the LayerNorm fold's consumer (q|k|v, fc1 + GELU) and staged producer (out, fc2) on
+    the MFMA 32x32x16 variants of gemm_nt_wide against the default 16x16x32 ones -- same operands, same K order per
+    accumulator, different accumulator / epilogue lane mapping: agreement to fp32 rounding of the epilogues."""
+    from perceiverio_pytorch_amd import _lib as L
+    from perceiverio_pytorch_amd.transformer_primitives import SelfAttention
+    lib = L.lib()
+    _policy(policy)
+    torch.manual_seed(9)
+    m = SelfAttention(1024, widening_factor=1, num_heads=8).to(dev).eval()
+    x = torch.randn(8, 512, 1024, device=dev) * 1.5 + 0.2
+    prev = lib.pio_gemm_kernel_override(0)
+    try:
+        y0 = m(x).double()
+        lib.pio_gemm_kernel_override(4)
+        y1 = m(x).double()
+    finally:
+        lib.pio_gemm_kernel_override(prev)
+    assert not torch.equal(y0, y1), "override 4 did not change the kernels"
+    assert ((y1 - y0).abs().max() / y0.abs().max()).item() <= 2e-4
+    assert ((y1 - y0).norm() / y0.norm()).item() <= 5e-5
