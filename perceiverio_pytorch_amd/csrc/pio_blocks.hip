@@ -156,9 +156,10 @@ static ScoreChunks score_chunks(int B, int H, int Tq, int Tk) {
 
 // true when attention_core will take a fused (score-free) kernel for every call that passes no full mask / bias /
 // probability output: the plans of the encoder / decoder (which never pass those) then carve no score buffers at all
-static bool fused_capable(const pio_attention_t &a) {
-    if (a.act_split == 2) return xattn_supported(a.dkp, a.dvp);  // split projections, single-sweep fused core
-    return !a.act_split && (flash_supported(a.dkp, a.dvp) || xattn_supported(a.dkp, a.dvp));
+static bool fused_capable(const pio_attention_t &a, int Tk) {
+    const bool cross = xattn_supported(a.dkp, a.dvp) || xtall_supported(a.dkp, a.dvp, Tk);
+    if (a.act_split == 2) return cross;  // split projections, single-sweep fused core
+    return !a.act_split && (flash_supported(a.dkp, a.dvp) || cross);
 }
 
 struct AttnScratch {
@@ -184,8 +185,11 @@ struct AttnScratch {
             p16 = take_pair(c, (size_t)ch.b_chunk * a.heads * ch.q_chunk * tkp, sp);
         }
         o16 = take_pair(c, (size_t)B * Tq * ldo, sp);
-        const size_t xb = (a.act_split != 1 && xattn_supported(a.dkp, a.dvp))
-                              ? xattn_partial_bytes(a.dkp, a.dvp, B, a.heads, Tq, Tk) : 0;
+        size_t xb = 0;
+        if (a.act_split != 1) {
+            if (xattn_supported(a.dkp, a.dvp)) xb = xattn_partial_bytes(a.dkp, a.dvp, B, a.heads, Tq, Tk);
+            else if (xtall_supported(a.dkp, a.dvp, Tk)) xb = xtall_scratch_bytes(B);
+        }
         xpart = xb ? c.take(xb) : nullptr;
     }
 };
@@ -298,6 +302,15 @@ static int attention_core(const pio_attention_t &a, Pair xq, bool q_bcast, Pair 
                              single_core ? w.o16.lo : nullptr, B, H, Tq, Tk, ldq, ldq,
                              tkv, ldo, q_bcast ? 0 : (int64_t)Tq * ldq, (int64_t)Tk * ldq, ldo * tkv, (int64_t)Tq * ldo,
                              kv_mask, q_mask, w.xpart, s));
+        return linear_fwd(a.o, a.dtype, w.o16, (int64_t)B * Tq, out, nullptr, true, a.out, a.out, 0, res, s);
+    }
+    if (score_free && xtall_supported(a.dkp, a.dvp, Tk)) {
+        // a head wider than the tiled kernel covers, over at most 512 keys (the ImageNet decoder: 1024 channels x 512
+        // latents): the score row of a query stays in registers, S is computed once
+        PIO_TRY(xtall_launch(a.dtype, a.dkp, a.dvp, a.dk, w.q16.hi, k_hi, w.vt16.hi, w.o16.hi,
+                             single_core ? w.o16.lo : nullptr, B, H, Tq, Tk, ldq, ldq, tkv, ldo,
+                             q_bcast ? 0 : (int64_t)Tq * ldq, (int64_t)Tk * ldq, ldo * tkv, (int64_t)Tq * ldo, kv_mask,
+                             q_mask, w.xpart, s));
         return linear_fwd(a.o, a.dtype, w.o16, (int64_t)B * Tq, out, nullptr, true, a.out, a.out, 0, res, s);
     }
     if (!w.scores) return PIO_E_WORKSPACE;  // (the plan promised a fused kernel)
@@ -447,7 +460,7 @@ struct SelfPlan {
         x16 = take_pair(c, (size_t)rows * cmax, sa.attn.act_split || sa.mlp.act_split);
         h16 = take_pair(c, (size_t)rows * pad8(sa.mlp.hidden), sa.mlp.act_split != 0);
         x1 = (float *)c.take((size_t)rows * sa.attn.out * 4);
-        core.carve(c, sa.attn, B, B, N, N, !(lean && fused_capable(sa.attn)));
+        core.carve(c, sa.attn, B, B, N, N, !(lean && fused_capable(sa.attn, N)));
         if (sa.fold.qkv.w_hi && sa.fold.fc1.w_hi) {
             x16b = c.take((size_t)rows * cmax * 2);
             lo_a = c.take((size_t)rows * cmax * 2);
@@ -571,7 +584,7 @@ struct CrossPlan {
         kv16 = take_pair(c, (size_t)B * Tk * pad8(ca.attn.k_in), ca.attn.act_split != 0);
         h16 = take_pair(c, (size_t)rows * pad8(ca.mlp.hidden), ca.mlp.act_split != 0);
         x1 = (float *)c.take((size_t)rows * ca.attn.out * 4);
-        core.carve(c, ca.attn, Bq, B, Tq, Tk, !(lean && fused_capable(ca.attn)));
+        core.carve(c, ca.attn, Bq, B, Tq, Tk, !(lean && fused_capable(ca.attn, Tk)));
         return c.off;
     }
 };

@@ -26,7 +26,14 @@ constexpr int BM = 128, BN = 128, BK = 64;   // the default tile (launcher arith
 // profilers report the two uses under different kernel names.
 // TM x TN: 128 x 128 (four waves of 64 x 64) or 64 x 64 (four waves of 32 x 32: problems whose 128 x 128 tiling would
 // leave most of the 256 CUs idle -- a 2048-row latent stack at batch 1 has 64 such tiles per GEMM).
-template <int DT, int KIND, int TM, int TN>
+// NS: operand stages in LDS.  2 = double buffer, the DMA of step t+1 against the MFMAs of step t (two workgroups per CU
+// hide each other's waits: the 128 x 128 tile on problems with many tiles).  6 (the 64 x 64 tile: problems of at most a
+// tile per CU, where nobody else covers a wait) = a RING: the pieces of step t+4 are issued at the top of step t, a
+// counted s_waitcnt vmcnt leaves four steps in flight across a raw s_barrier, every wave issues the same number of
+// pieces per step (steps past the end re-read valid memory into the slot the ring would use next: never read) -- with
+// the double buffer a 64 x 64 x 1024 tile spent ~1.9 k cycles per 64-deep step (the latency of one LDS-DMA round trip
+// under load) on 128 cycles of MFMAs.
+template <int DT, int KIND, int TM, int TN, int NS>
 __global__ __launch_bounds__(256) void gemm_nt_128(const GemmParams p) {
     typedef typename Op<DT>::T T;
     typedef typename Op<DT>::V8 V8;
@@ -34,8 +41,9 @@ __global__ __launch_bounds__(256) void gemm_nt_128(const GemmParams p) {
     constexpr int A_PPW = TM / 32, B_PPW = TN / 32;                  // 1-KiB pieces (8 rows) per wave
     constexpr int MI = TM / 32, NI = TN / 32;                        // 16 x 16 units per wave (waves as 2 x 2)
     constexpr int EPI_BYTES = TM * TN * 4;
-    constexpr int SMEM = 2 * (A_BYTES + B_BYTES) > EPI_BYTES ? 2 * (A_BYTES + B_BYTES) : EPI_BYTES;
-    __shared__ __attribute__((aligned(16))) char smem[SMEM];        // A0 A1 B0 B1 (then the epilogue image)
+    constexpr int SMEM = NS * (A_BYTES + B_BYTES) > EPI_BYTES ? NS * (A_BYTES + B_BYTES) : EPI_BYTES;
+    static_assert(NS == 2 || (NS - 2) * (A_PPW + B_PPW) <= 63, "the counted wait must fit vmcnt");
+    __shared__ __attribute__((aligned(16))) char smem[SMEM];        // A stages, B stages (then the epilogue image)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -85,7 +93,7 @@ __global__ __launch_bounds__(256) void gemm_nt_128(const GemmParams p) {
         const int64_t dA = pass == 0 ? 0 : (pass == 1 ? p.dA1 : p.dA2);
         const int64_t dB = pass == 0 ? 0 : (pass == 1 ? p.dB1 : p.dB2);
         char *abase = smem + buf * A_BYTES;
-        char *bbase = smem + 2 * A_BYTES + buf * B_BYTES;
+        char *bbase = smem + NS * A_BYTES + buf * B_BYTES;
 #pragma unroll
         for (int i = 0; i < A_PPW; ++i) {
             const T *sa = (k0 + a_koff[i]) < p.K ? (a_src[i] + k0 + dA) : zsrc;
@@ -118,13 +126,32 @@ __global__ __launch_bounds__(256) void gemm_nt_128(const GemmParams p) {
 #pragma unroll
     for (int i = 0; i < NI; ++i) b_off[i] = (wn * (TN / 2) + i * 16 + frow) * 128;
 
-    stage(0, 0);
+    if constexpr (NS == 2) stage(0, 0);
+    else {
+        // ring prologue: steps 0 .. NS-2 in flight (a step past the end repeats step 0's valid sources: the counts stay
+        // exact, the slot is never read)
+#pragma unroll
+        for (int j = 0; j < NS - 1; ++j) stage(j < nk ? j : 0, j);
+    }
+    int slot = 0;  // (NS > 2) ring slot of step kt
     for (int kt = 0; kt < nk; ++kt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
-        const char *abase = smem + (kt & 1) * A_BYTES;
-        const char *bbase = smem + 2 * A_BYTES + (kt & 1) * B_BYTES;
+        if constexpr (NS == 2) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
+        } else {
+            // all but the youngest NS-2 steps' pieces have landed: step kt is complete in this wave's share, after the
+            // barrier in every wave's; and every wave has left step kt-1 (its fragment reads were consumed by its
+            // MFMAs), whose slot takes step kt+NS-1.  A raw s_barrier: __syncthreads() would drain vmcnt to zero.
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * (A_PPW + B_PPW)) : "memory");
+            __builtin_amdgcn_s_barrier();
+            const int nslot = slot == 0 ? NS - 1 : slot - 1;
+            stage(kt + NS - 1 < nk ? kt + NS - 1 : 0, nslot);
+        }
+        const int cur = NS == 2 ? (kt & 1) : slot;
+        if constexpr (NS != 2) slot = slot + 1 == NS ? 0 : slot + 1;
+        const char *abase = smem + cur * A_BYTES;
+        const char *bbase = smem + NS * A_BYTES + cur * B_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int coff = ((ks * 4 + fchunk) ^ fswz) << 4;
@@ -144,6 +171,7 @@ __global__ __launch_bounds__(256) void gemm_nt_128(const GemmParams p) {
     // [TM][TN] fp32 image (16-byte chunks XOR-swizzled by row, conflict-free both ways) so that the
     // bias / GELU / residual / store pass walks whole rows: a wave touches 2 rows x 512 contiguous bytes
     // (fp32) or 2 rows x 256 bytes (16-bit) per instruction instead of 16 rows x 64 bytes.
+    if constexpr (NS != 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the ring's surplus pieces: land before the image)
     __syncthreads();  // every wave is done reading the last operand tile
     float *cs = (float *)smem;
     constexpr int CPR = TN / 4;  // 16-byte chunks per image row (32 or 16)
@@ -261,6 +289,21 @@ int gemm_kernel_override(int which) {
     return prev;
 }
 
+// Dev aid: PIO_GEMM_LOG=1 prints one line per launch (shape, sweeps, epilogue form, kernel chosen) to stderr.
+static bool gemm_log_on() {
+    static const bool on = [] {
+        const char *e = getenv("PIO_GEMM_LOG");
+        return e && atoi(e) != 0;
+    }();
+    return on;
+}
+static void gemm_log(const char *kernel, const pio_gemm_t &g, const GemmParams &p) {
+    if (!gemm_log_on()) return;
+    fprintf(stderr, "pio_gemm %-10s M=%d N=%d K=%d batch=%d npass=%d act=%d out_f32=%d res=%d fold=%s n_store=%d\n", kernel, g.M,
+            g.N, g.K, g.batch, p.npass, g.act, g.out_f32, (g.R || g.R16_hi) ? 1 : 0,
+            g.ln_part ? "consumer" : (g.row_part ? "producer" : "-"), p.n_store);
+}
+
 int gemm_nt_launch(const pio_gemm_t &g, hipStream_t s) {
     if (!g.A || !g.B) return PIO_E_ARG;
     if (!g.C && !(g.X16 && g.X16_lo && g.out_f32)) return PIO_E_ARG;  // (fp32 C is optional beside a 16-bit pair)
@@ -370,6 +413,7 @@ int gemm_nt_launch(const pio_gemm_t &g, hipStream_t s) {
                 }();
                 if ((forced == 3 || (forced == 0 && duo_env)) && gemm_duo_ok(p, g.batch)) {
                     ProfScope prof(PROF_GEMM_WIDE, algo_flops, algo_bytes, s);
+                    gemm_log("duo", g, p);
                     gemm_duo_launch(p, g.dtype, s);
                     return launch_status();
                 }
@@ -378,6 +422,7 @@ int gemm_nt_launch(const pio_gemm_t &g, hipStream_t s) {
             }
             if (wide && gemm_wide_ok(p, g.batch)) {
                 ProfScope prof(PROF_GEMM_WIDE, algo_flops, algo_bytes, s);
+                gemm_log("wide", g, p);
                 gemm_wide_launch(p, g.dtype, s);
                 return launch_status();
             }
@@ -394,6 +439,7 @@ int gemm_nt_launch(const pio_gemm_t &g, hipStream_t s) {
             if (forced == 128 || forced == 256) stream = false;
             if (stream && gemm_stream_ok(p, g.batch)) {
                 ProfScope prof(PROF_GEMM_STREAM, algo_flops, algo_bytes, s);
+                gemm_log("stream", g, p);
                 gemm_stream_launch(p, g.dtype, g.batch, s);
                 return launch_status();
             }
@@ -401,6 +447,7 @@ int gemm_nt_launch(const pio_gemm_t &g, hipStream_t s) {
         if (big) {
             ProfScope prof(PROF_GEMM_LINEAR, algo_flops, algo_bytes, s);  // class 0 == kernel gemm_nt_256
             p.tiles_n = tn256;
+            gemm_log("t256", g, p);
             gemm256_launch(p, g.dtype, attn, tm256, tn256, g.batch, s);
             return launch_status();
         }
@@ -410,14 +457,15 @@ int gemm_nt_launch(const pio_gemm_t &g, hipStream_t s) {
     // stack of the flow model at B = 1 has 64 tiles of 128 x 128 per GEMM, 256 of 64 x 64); override 64 forces them
     const int64_t tiles128 = (int64_t)tiles_m * p.tiles_n * g.batch;
     const bool small = gemm_kernel_choice() == 64 || (gemm_kernel_choice() == 0 && tiles128 < 192);
+    gemm_log(small ? "t64" : "t128", g, p);
     if (small) {
         p.tiles_n = (p.n_store + 63) / 64;
         grid = dim3((unsigned)(((g.M + 63) / 64) * p.tiles_n), (unsigned)g.batch, 1);
     }
 #define PIO_G128(DTV, KINDV)                                                                            \
     do {                                                                                                \
-        if (small) hipLaunchKernelGGL((gemm_nt_128<DTV, KINDV, 64, 64>), grid, block, 0, s, p);         \
-        else hipLaunchKernelGGL((gemm_nt_128<DTV, KINDV, 128, 128>), grid, block, 0, s, p);             \
+        if (small) hipLaunchKernelGGL((gemm_nt_128<DTV, KINDV, 64, 64, 6>), grid, block, 0, s, p);      \
+        else hipLaunchKernelGGL((gemm_nt_128<DTV, KINDV, 128, 128, 2>), grid, block, 0, s, p);          \
     } while (0)
     if (g.dtype == PIO_DT_F16) {
         if (attn) PIO_G128(PIO_DT_F16, 1);

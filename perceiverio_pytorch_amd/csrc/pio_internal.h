@@ -118,6 +118,14 @@ int xattn_launch(int dtype, int dkp, int dvp, int dk_logical, const void *Q, con
                  void *O_lo, int B, int H, int Tq, int Tk, int64_t ldq, int64_t ldk, int64_t ldvt, int64_t ldo, int64_t sQb,
                  int64_t sKb, int64_t sVb, int64_t sOb, const uint8_t *kv_mask, const uint8_t *q_mask, void *partials,
                  hipStream_t s);
+// fused cross-attention for a head wider than the key axis is long (pio_xtall.hip): Tk <= 512, S computed once per query
+// row and kept in registers (the ImageNet decoder's 1024-wide head over 512 latents)
+bool xtall_supported(int dkp, int dvp, int Tk);
+size_t xtall_scratch_bytes(int B);  // key-bit words of a masked launch
+int xtall_launch(int dtype, int dkp, int dvp, int dk_logical, const void *Q, const void *K, const void *VT, void *O,
+                 void *O_lo, int B, int H, int Tq, int Tk, int64_t ldq, int64_t ldk, int64_t ldvt, int64_t ldo, int64_t sQb,
+                 int64_t sKb, int64_t sVb, int64_t sOb, const uint8_t *kv_mask, const uint8_t *q_mask, void *scratch,
+                 hipStream_t s);
 // eval BatchNorm -> ReLU -> 3x3/2 SAME max-pool -> channels-last tokens (tail of Conv2DDownsample)
 int bn_relu_pool_nhwc_launch(const float *x, const float *scale, const float *shift, float *y, int B, int C, int H, int W,
                              int pad_top, int pad_left, hipStream_t s);

@@ -454,6 +454,13 @@ __global__ __launch_bounds__(256) void xattn_keybits_kernel(const uint8_t *kv_ma
     if (j == 0 && w < total_words) bits[w] = (threadIdx.x & 32) ? (uint32_t)(bal >> 32) : (uint32_t)bal;
 }
 
+// (shared with pio_xtall.hip)
+void xattn_keybits_launch(const uint8_t *kv_mask, uint32_t *bits, int B, int Tk, int ntiles, hipStream_t s) {
+    const int64_t words = (int64_t)B * ntiles;
+    hipLaunchKernelGGL(xattn_keybits_kernel, dim3((unsigned)((words + 7) / 8)), dim3(256), 0, s, kv_mask, bits, Tk, ntiles,
+                       words);
+}
+
 // Combines the key splits of one (batch, head, query row): O = sum_s O_s 2^(m_s - M) / sum_s l_s 2^(m_s - M).
 template <int DT>
 __global__ __launch_bounds__(256) void xattn_reduce_kernel(const float *part_o, const float *part_ml, void *O, void *O_lo,

@@ -878,6 +878,12 @@ XATTN_CASES = [
     (1, 322, 322, 2, 1, 5, "key", False),          # edge: one query row, fewer keys than one 32-key tile
     (8, 32, 96, 1, 3, 33, "query", False),         # edge: a second tile holding a single key
     (1, 512, 512, 2, 129, 31, None, True),         # edge: ragged query tile, Tk = tile - 1, broadcast Q
+    # heads wider than the tiled kernel covers, over <= 512 keys: xattn_tall_kernel (pio_xtall.hip; the ImageNet decoder)
+    (1, 1024, 1024, 2, 300, 512, None, True),      # the decoder's shape class: broadcast Q, ragged last query tile
+    (1, 1024, 1024, 2, 200, 480, "key", False),    # key mask words + a tail past Tk inside the last 32-key block
+    (1, 1024, 1024, 2, 77, 100, "query", False),   # Tk far below 512: clamped K rows / V^T columns, wiped query rows
+    (1, 768, 512, 3, 130, 257, "key_allfalse_b1", True),   # dk != dv, a key block holding one key, a sample without keys
+    (2, 800, 256, 1, 33, 512, None, False),        # two heads, dk = 25 chunks of 32, one dv pass
 ]
 
 

@@ -15,6 +15,7 @@ SHAPES = {  # name: heads, dk, dv, B, Tq, Tk, q_in, kv_in, broadcast q
     "imagenet_enc": (1, 322, 322, 32, 512, 3136, 1024, 322, True),
     "flow_enc": (1, 322, 322, 1, 2048, 182528, 512, 322, True),
     "flow_dec": (1, 512, 512, 1, 182528, 2048, 322, 512, False),
+    "imagenet_dec": (1, 1024, 1024, 32, 1000, 512, 1024, 1024, True),    # xattn_tall_kernel (pio_xtall.hip)
     "multimodal_enc": (1, 704, 704, 1, 784, 52097, 512, 704, True),
     "multimodal_dec": (1, 512, 512, 1, 6288, 784, 1026, 512, False),
     "language_enc": (8, 32, 160, 32, 256, 2048, 1280, 768, True),
