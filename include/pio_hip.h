@@ -111,6 +111,12 @@ typedef struct pio_ln_fold_t {
     const float *qkv_c;
     pio_linear_t fc1;
     const float *fc1_c;
+    /* Range guard of the folded stack (optional device word, zeroed by the caller): inside the fold the residual stream
+     * is a 16-bit pair, so an activation beyond the operand range (fp16: 65504) turns into inf / NaN there.  Every GEMM
+     * that produces the stream ORs 1 into *range_flag when a row statistic of its result is not finite -- no extra
+     * kernel, no host synchronisation; the caller reads the word when it next synchronises anyway and re-runs the call
+     * un-folded (PIO_E_RANGE if that does not help).  NULL: not reported. */
+    int32_t *range_flag;
 } pio_ln_fold_t;
 
 /* SelfAttention (transformer_primitives.py:219-297) */
@@ -270,6 +276,8 @@ typedef struct pio_gemm_t {
     /* B_lo holds rows (= output columns) [b_lo_n0, N) only: the extra sweep C += A B_lo^T runs for those columns
      * alone.  0 = all rows.  Multiple of 256; kernel gemm_nt_wide only (else PIO_E_SHAPE). */
     int32_t b_lo_n0;
+    /* LayerNorm-fold producer only (optional): *range_flag |= 1 when a row's (sum, sum of squares) is not finite */
+    int32_t *range_flag;
 } pio_gemm_t;
 int pio_gemm_nt(const pio_gemm_t *g, void *stream);
 

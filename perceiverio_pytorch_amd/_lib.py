@@ -48,7 +48,8 @@ class Mlp(C.Structure):
 
 
 class LnFold(C.Structure):
-    _fields_ = [("qkv", Linear), ("qkv_c", C.c_void_p), ("fc1", Linear), ("fc1_c", C.c_void_p)]
+    _fields_ = [("qkv", Linear), ("qkv_c", C.c_void_p), ("fc1", Linear), ("fc1_c", C.c_void_p),
+                ("range_flag", C.c_void_p)]
 
 
 class SelfAttention(C.Structure):
@@ -79,7 +80,8 @@ class Gemm(C.Structure):
                 ("dtype", C.c_int32),
                 ("X16", C.c_void_p), ("ld16", C.c_int64), ("row_part", C.c_void_p), ("ln_part", C.c_void_p),
                 ("ln_c", C.c_void_p), ("ln_eps", C.c_float),
-                ("X16_lo", C.c_void_p), ("R16_hi", C.c_void_p), ("R16_lo", C.c_void_p), ("b_lo_n0", C.c_int32)]
+                ("X16_lo", C.c_void_p), ("R16_hi", C.c_void_p), ("R16_lo", C.c_void_p), ("b_lo_n0", C.c_int32),
+                ("range_flag", C.c_void_p)]
 
 
 # name -> (restype, argtypes); must list EVERY function declared in include/pio_hip.h

@@ -70,6 +70,7 @@ struct LnFold {
     // fp32 output pointer of the GEMM may be null
     void *out16_lo = nullptr;
     const void *res16_hi = nullptr, *res16_lo = nullptr;
+    int32_t *range_flag = nullptr;  // producer: the caller's range-guard word (pio_ln_fold_t.range_flag)
 };
 
 // y[rows, n] = x16[rows, lin.k] * W^T (+bias) (act) (+R); a 16-bit output has ldc = lin.n (padded).
@@ -90,6 +91,7 @@ static int linear_fwd(const pio_linear_t &lin_plain, int dtype, Pair x, int64_t 
         g.X16_lo = fold->out16_lo;
         g.R16_hi = fold->res16_hi;
         g.R16_lo = fold->res16_lo;
+        g.range_flag = fold->range_flag;
     }
     g.A = x.hi;
     g.A_lo = x.lo;
@@ -532,6 +534,7 @@ static int self_attention_run(const pio_self_attention_t &sa, const pio_tensor3_
         f_qkv.in_part = p.part_a; f_qkv.w = &sa.fold.qkv; f_qkv.c = sa.fold.qkv_c; f_qkv.eps = sa.ln1.eps;
         f_out.out16 = p.x16b; f_out.ld16 = x.C; f_out.out_part = p.part_b;
         f_out.out16_lo = p.lo_b; f_out.res16_hi = p.x16.hi; f_out.res16_lo = p.lo_a;
+        f_out.range_flag = f_fc2.range_flag = sa.fold.range_flag;
         f_fc1.in_part = p.part_b; f_fc1.w = &sa.fold.fc1; f_fc1.c = sa.fold.fc1_c; f_fc1.eps = sa.ln2.eps;
         f_fc2.out16 = p.x16.hi; f_fc2.ld16 = x.C; f_fc2.out_part = p.part_a;
         f_fc2.out16_lo = p.lo_a; f_fc2.res16_hi = p.x16b; f_fc2.res16_lo = p.lo_b;

@@ -342,6 +342,7 @@ int gemm_nt_launch(const pio_gemm_t &g, hipStream_t s) {
     p.X16 = g.X16; p.ld16 = g.ld16; p.row_part = g.row_part;
     p.ln_part = g.ln_part; p.ln_c = g.ln_c; p.ln_eps = g.ln_eps;
     p.X16_lo = g.X16_lo; p.R16_hi = g.R16_hi; p.R16_lo = g.R16_lo;
+    p.range_flag = g.row_part ? g.range_flag : nullptr;
     p.lo_n0 = g.B_lo ? g.b_lo_n0 : 0;
     {
         // A/B switch: env PIO_WIDE_STAGED_EPI=0 keeps the direct (16 rows x 64 bytes per instruction) epilogue
@@ -464,7 +465,7 @@ int gemm_nt_launch(const pio_gemm_t &g, hipStream_t s) {
     }
 #define PIO_G128(DTV, KINDV)                                                                            \
     do {                                                                                                \
-        if (small) hipLaunchKernelGGL((gemm_nt_128<DTV, KINDV, 64, 64, 6>), grid, block, 0, s, p);      \
+        if (small) hipLaunchKernelGGL((gemm_nt_128<DTV, KINDV, 64, 64, 4>), grid, block, 0, s, p);      \
         else hipLaunchKernelGGL((gemm_nt_128<DTV, KINDV, 128, 128, 2>), grid, block, 0, s, p);          \
     } while (0)
     if (g.dtype == PIO_DT_F16) {

@@ -35,6 +35,7 @@ struct GemmParams {
     float ln_eps;
     void *X16_lo;
     const void *R16_hi, *R16_lo;
+    int *range_flag;  // producer: set to 1 when a row statistic is not finite (the folded stack's fp16 range guard)
 };
 
 

@@ -625,6 +625,9 @@ __global__ __launch_bounds__(256) void gemm_nt_wide(const GemmParams p, int tile
                             float *dstp = part + (int64_t)(mi * 16 + st * 4) * (p.N >> 7) * 2;
                             dstp[0] = rsum;
                             dstp[1] = rsq;
+                            // range guard of the folded stack: an overflowed 16-bit half shows as a non-finite sum
+                            // (rare store; an extra vector-memory operation only makes the counted waits stricter)
+                            if (p.range_flag && !(rsq <= 3.0e38f)) *p.range_flag = 1;
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -751,6 +754,7 @@ __global__ __launch_bounds__(256) void gemm_nt_wide(const GemmParams p, int tile
                         float *dstp = p.row_part + ((int64_t)m * (p.N >> 7) + (o_n0 >> 7)) * 2;
                         dstp[0] = rsum;
                         dstp[1] = rsq;
+                        if (p.range_flag && !(rsq <= 3.0e38f)) *p.range_flag = 1;
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }

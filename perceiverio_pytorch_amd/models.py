@@ -320,7 +320,8 @@ class MultiModalPerceiver(nn.Module):
             else:
                 if cached is None:
                     x, sizes, without_pos = P._multi_preprocessor(inputs, pos=None)
-                    cached = (x, sizes, without_pos, P._encoder(x, P._encoder.latents(x)))
+                    with precision(P.encoder_policy):
+                        cached = (x, sizes, without_pos, P._encoder(x, P._encoder.latents(x)))
                 x, sizes, without_pos, latents = cached
                 query, qsizes = P.decoder_query(x, sizes, without_pos, subsampled_points=points)
                 from .perceiver import restructure

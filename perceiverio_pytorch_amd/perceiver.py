@@ -76,31 +76,24 @@ class PerceiverEncoder(nn.Module):
         im, im_ptr = R.mask_u8(input_mask, (B, M), dev)
         out = torch.empty((B, N, D), dtype=torch.float32, device=dev)
         tail3 = R.tensor3(inputs_tail) if inputs_tail is not None else None
+        # fp16 range guard of the LayerNorm-folded stack (runtime.range_check): the GEMMs that produce the folded residual
+        # stream report a non-finite row statistic into a device word (pio_ln_fold_t.range_flag) -- whatever policy or
+        # branch the fold is taken under, and only when it IS taken
+        guard = R.range_check() and Lyr > 0 and not self._range_fallback
+        flag = None
+        if guard:
+            flag = R.range_flag(dev)
+            flag.zero_()
+            for i in range(Lyr):
+                layers[i].fold.range_flag = flag.data_ptr()
         nsplit = R.batch_streams()
         if nsplit <= 1 or B < 2 * nsplit or B % nsplit or inputs_tail is not None:
             ws = R.workspace(dev, lib.pio_encoder_workspace_bytes(cross, layers, Lyr, B, M, N))
-
-            def run():
-                with R.on_device(dev):
-                    L.check(lib.pio_encoder_fwd_split(cross, layers, Lyr, self._num_blocks, R.tensor3(x), tail3,
-                                                      R.tensor3(z0), im_ptr, out.data_ptr(), ws.data_ptr(),
-                                                      ws.numel(), R.stream_ptr(dev)), "pio_encoder_fwd")
-            run()
-            # fp16 range guard of the LayerNorm-folded stack (runtime.range_check): the fold is offered for 1024-channel
-            # stacks with >= 2048 rows under the single-sweep policies (pio_ln_fold_t)
-            dtype, wlevel, split = R.policy_dtype()
-            if (R.range_check() and Lyr > 0 and wlevel == 0 and not split and D == 1024 and B * N >= 2048
-                    and not bool(torch.isfinite(out).all())):
-                prev = lib.pio_ln_fold_enable(0)
-                try:
-                    run()
-                finally:
-                    lib.pio_ln_fold_enable(prev)
-                if not bool(torch.isfinite(out).all()):
-                    raise L.PioError("PerceiverEncoder.forward: PIO_E_RANGE -- non-finite latents with and without the "
-                                     "LayerNorm fold: activations exceed the fp16 operand range (65504); use the "
-                                     "precision policy 'bf16x3' for this model")
-            return R.forward_only(out, inputs, latents, *self.parameters())
+            with R.on_device(dev):
+                L.check(lib.pio_encoder_fwd_split(cross, layers, Lyr, self._num_blocks, R.tensor3(x), tail3,
+                                                  R.tensor3(z0), im_ptr, out.data_ptr(), ws.data_ptr(),
+                                                  ws.numel(), R.stream_ptr(dev)), "pio_encoder_fwd")
+            return self._finish(out, flag, inputs, inputs_tail, latents, input_mask)
         # Samples are independent: run `nsplit` batch slices as independent kernel chains on side streams so that
         # one chain's fill / drain / HBM-bound kernels overlap the other's MFMA-bound ones (each slice still fills
         # >= half of the CUs).  Every slice has its own workspace; the current stream waits for all of them.
@@ -129,7 +122,39 @@ class PerceiverEncoder(nn.Module):
         for t in (x, z0, out):
             for side in R.side_streams(dev, nsplit):
                 t.record_stream(side)
+        return self._finish(out, flag, inputs, inputs_tail, latents, input_mask)
+
+    _range_fallback = False   # True while the call is being repeated un-folded (the guard's fallback)
+
+    def _finish(self, out, flag, inputs, inputs_tail, latents, input_mask):
+        """Range guard, host side.  Inside PerceiverIO.forward the check is deferred to the end of the forward (no
+        synchronisation between encoder and decoder); called on its own the encoder resolves it here; during stream
+        capture nobody reads the word (runtime.last_range_flag)."""
+        if self._range_fallback:
+            # the un-folded repeat: nothing reports into a word here, so look at the result itself (rare path)
+            if not bool(torch.isfinite(out).all()):
+                raise L.PioError("PerceiverEncoder.forward: PIO_E_RANGE -- non-finite latents with and without the "
+                                 "LayerNorm fold: activations exceed the fp16 operand range (65504); use the "
+                                 "precision policy 'bf16x3' for this model")
+        elif flag is not None and not R.capturing(out.device):
+            pend = R.range_deferred()
+            if pend is not None:
+                pend.append(flag)
+            elif int(flag.item()) != 0:
+                full = inputs if inputs_tail is None else (inputs, inputs_tail)
+                return self.forward_unfolded(full, latents, input_mask=input_mask)
         return R.forward_only(out, inputs, latents, *self.parameters())
+
+    def forward_unfolded(self, inputs, latents, *, input_mask=None):
+        """The same call with the LayerNorm fold off (fp32 residual stream): the range guard's fallback."""
+        lib = L.lib()
+        prev = lib.pio_ln_fold_enable(0)
+        self._range_fallback = True
+        try:
+            return self.forward(inputs, latents, input_mask=input_mask)
+        finally:
+            self._range_fallback = False
+            lib.pio_ln_fold_enable(prev)
 
 
 class PerceiverDecoder(nn.Module):
@@ -378,7 +403,29 @@ class PerceiverIO(nn.Module):
                 query_shard=None):
         """Reference signature (perceiver.py:287-288) plus `query_shard=(rank, world)`: decode only this rank's slice
         of the query rows and all-gather the result along the query axis (dist.decode_query_sharded) -- the
-        multi-GPU form for batches smaller than the world (optical flow).  Needs an initialised process group."""
+        multi-GPU form for batches smaller than the world (optical flow).  Needs an initialised process group.
+
+        The fp16 range guard of the folded latent stack (runtime.range_check) is resolved HERE, once, after everything
+        has been enqueued: the encoder's kernels report into a device word, nothing synchronises between encoder and
+        decoder, and the word is read where the caller is about to consume the outputs.  A set word repeats the
+        forward with the fold off (PIO_E_RANGE if that does not help)."""
+        kw = dict(subsampled_output_points=subsampled_output_points, pos=pos, input_mask=input_mask,
+                  query_mask=query_mask, query_shard=query_shard)
+        with R.defer_range_checks() as guard:
+            outputs = self._forward(inputs, **kw)
+        if guard.pending and any(int(f.item()) != 0 for f in guard.pending):
+            lib = L.lib()
+            prev = lib.pio_ln_fold_enable(0)
+            self._encoder._range_fallback = True
+            try:
+                outputs = self._forward(inputs, **kw)
+            finally:
+                self._encoder._range_fallback = False
+                lib.pio_ln_fold_enable(prev)
+        return outputs
+
+    def _forward(self, inputs, *, subsampled_output_points=None, pos=None, input_mask=None, query_mask=None,
+                 query_shard=None):
         if type(inputs) is torch.Tensor:
             inputs = {"__default": inputs}
         split = self._split_input(inputs, pos) if self.split_encoder_input else None

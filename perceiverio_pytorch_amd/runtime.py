@@ -79,13 +79,20 @@ def policy_dtype(name: Optional[str] = None) -> Tuple[int, bool, bool]:
 # ------------------------------------------------------------------------------------------------
 # range guard of the LayerNorm-folded stack.  Inside it the residual stream is an fp16 PAIR (hi + lo) and the GEMMs
 # read the un-normalised hi half: a latent beyond +-65504 becomes inf (the un-folded path keeps the stream in fp32 and
-# only ever rounds LayerNorm OUTPUTS, which are O(1)).  With the guard on (default; PIO_RANGE_CHECK=0 or
-# set_range_check(False) turns it off) PerceiverEncoder.forward checks the stack's output for non-finite values when
-# the fold was eligible, re-runs the call with the fold off if it finds any, and raises PIO_E_RANGE if that does not
-# help (then the model needs a wider operand type: precision policy "bf16x3").  Cost: one reduction over the latents
-# and a host sync per encoder call.
+# only ever rounds LayerNorm OUTPUTS, which are O(1)).  The guard lives ON THE DEVICE: every GEMM that produces the
+# folded stream already reduces each result row's (sum, sum of squares) and ORs 1 into a device word when one of them
+# is not finite (pio_ln_fold_t.range_flag) -- no extra kernel, no host synchronisation inside the forward.  With the
+# guard on (default; PIO_RANGE_CHECK=0 or set_range_check(False) turns it off) the word is read
+#   * by PerceiverIO.forward ONCE, after the decoder and the postprocessors have been enqueued (the point where the
+#     caller is about to consume the result), or
+#   * by PerceiverEncoder.forward itself when it is called on its own;
+# a set word re-runs the call with the fold off and raises PIO_E_RANGE if the un-folded result is not finite either
+# (then the model needs a wider operand type: precision policy "bf16x3").  During stream capture nothing is read:
+# the word stays in `last_range_flag()` for the owner of the graph to look at after a replay.
 # ------------------------------------------------------------------------------------------------
 _range_check = os.environ.get("PIO_RANGE_CHECK", "1") != "0"
+_range_flags: Dict[int, torch.Tensor] = {}
+_range_deferred: Optional[list] = None      # not None: PerceiverIO.forward collects the encoder's pending checks
 
 
 def range_check() -> bool:
@@ -95,6 +102,49 @@ def range_check() -> bool:
 def set_range_check(on: bool) -> None:
     global _range_check
     _range_check = bool(on)
+
+
+def range_flag(device: torch.device) -> torch.Tensor:
+    """The device word the folded stack reports into (one per device, int32[1])."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    t = _range_flags.get(idx)
+    if t is None:
+        with torch.inference_mode(False):     # (a normal tensor: zeroed in place from inside and outside inference mode)
+            t = torch.zeros(1, dtype=torch.int32, device=device)
+        _range_flags[idx] = t
+    return t
+
+
+def last_range_flag(device: Optional[torch.device] = None) -> Optional[torch.Tensor]:
+    idx = (device.index if device is not None and device.index is not None else torch.cuda.current_device())
+    return _range_flags.get(idx)
+
+
+class defer_range_checks:
+    """PerceiverIO.forward: the encoder registers its pending check here instead of synchronising mid-forward."""
+
+    def __enter__(self):
+        global _range_deferred
+        self._saved = _range_deferred
+        _range_deferred = []
+        self.pending = _range_deferred
+        return self
+
+    def __exit__(self, *exc):
+        global _range_deferred
+        _range_deferred = self._saved
+        return False
+
+
+def range_deferred() -> Optional[list]:
+    return _range_deferred
+
+
+def capturing(device: torch.device) -> bool:
+    try:
+        return bool(torch.cuda.is_current_stream_capturing())
+    except Exception:  # noqa: BLE001
+        return False
 
 
 def policy_core_single(name: Optional[str] = None) -> bool:

@@ -970,7 +970,7 @@ def test_fused_cross_attention_vs_oracle(dev, case, policy):
 # ----------------------------------------------------------------------------------------------------
 # fp16 range: the LayerNorm-folded stack carries the residual stream as an fp16 pair
 # ----------------------------------------------------------------------------------------------------
-def _fold_stack(dev, scale, offset=0.0, outlier=0.0):
+def _fold_stack(dev, scale, offset=0.0, outlier=0.0, policy="fp16"):
     """A 1024-channel PerceiverEncoder (2 shared layers x 2 blocks) on 2048 latent rows whose latent table is scaled /
     shifted: returns (folded fp16, un-folded fp16, fp16x3) outputs and whether the guard re-ran the call."""
     from perceiverio_pytorch_amd import runtime as R
@@ -990,7 +990,7 @@ def _fold_stack(dev, scale, offset=0.0, outlier=0.0):
     outs = {}
     prev = lib.pio_ln_fold_enable(1)
     try:
-        _policy("fp16")
+        _policy(policy)
         outs["fold"] = enc(x, enc.latents(x)).clone()
         lib.pio_ln_fold_enable(0)
         outs["plain"] = enc(x, enc.latents(x)).clone()
@@ -1002,21 +1002,70 @@ def _fold_stack(dev, scale, offset=0.0, outlier=0.0):
     return outs
 
 
-def test_fold_range_guard_falls_back_on_overflow(dev):
+@pytest.mark.parametrize("policy", ["fp16", "fp16x2s", "fp16x2w"])
+def test_fold_range_guard_falls_back_on_overflow(dev, policy):
     """Latents beyond the fp16 range (65504): the folded stack alone would return inf / nan; with the guard
-    (runtime.range_check, default on) the call is re-run un-folded and matches the un-folded result bit for bit."""
+    (runtime.range_check, default on: a device word the fold's producer GEMMs report into) the call is re-run un-folded
+    and matches the un-folded result bit for bit -- under EVERY policy the fold is offered for."""
     from perceiverio_pytorch_amd import runtime as R
     assert R.range_check()
-    outs = _fold_stack(dev, scale=3.0e5)                       # |latents| up to ~1e6 >> 65504
+    outs = _fold_stack(dev, scale=3.0e5, policy=policy)        # |latents| up to ~1e6 >> 65504
     assert torch.isfinite(outs["fold"]).all(), "the guard must have replaced the overflowed result"
     assert torch.equal(outs["fold"], outs["plain"])
-    _assert_close(outs["plain"], outs["x3"].cpu().numpy(), TOL, what="un-folded fp16 vs fp16x3 at |x| ~ 1e6")
+    _assert_close(outs["plain"], outs["x3"].cpu().numpy(), TOL, what=f"un-folded {policy} vs fp16x3 at |x| ~ 1e6")
     R.set_range_check(False)
     try:
-        raw = _fold_stack(dev, scale=3.0e5)["fold"]
+        raw = _fold_stack(dev, scale=3.0e5, policy=policy)["fold"]
     finally:
         R.set_range_check(True)
     assert not torch.isfinite(raw).all(), "without the guard the fp16-pair stream overflows (documented behaviour)"
+    # in-range latents leave the word untouched
+    _fold_stack(dev, scale=1.0, policy=policy)
+    assert int(R.last_range_flag(dev).item()) == 0
+
+
+def test_range_guard_is_deferred_and_graph_capturable(dev):
+    """PerceiverIO.forward resolves the range guard once, after the decoder (no synchronisation between encoder and
+    decoder), and the whole module forward -- guard ON -- captures into a HIP graph: during capture nothing is read
+    from the device, the word stays in runtime.last_range_flag for the owner of the graph."""
+    from perceiverio_pytorch_amd import runtime as R
+    from perceiverio_pytorch_amd.perceiver import PerceiverIO
+    from perceiverio_pytorch_amd.output_queries import TrainableQuery
+    assert R.range_check()
+    torch.manual_seed(5)
+    m = PerceiverIO(num_blocks=2, num_self_attends_per_block=2, num_latents=512, num_latent_channels=1024,
+                    final_project=True, final_project_out_channels=16, input_channels=64,
+                    output_queries=TrainableQuery(output_index_dims=8, num_channels=1024)).to(dev).eval()
+    x = torch.randn(4, 96, 64, device=dev)                       # 4 x 512 = 2048 latent rows: the fold is active
+    _policy("fp16")
+    try:
+        with torch.inference_mode():
+            y = m(x).clone()
+            assert torch.isfinite(y).all()
+            # (a) overflow inside PerceiverIO.forward: deferred check, un-folded repeat of the whole forward
+            with torch.no_grad():
+                saved = m._encoder.latent_pos_enc.pos_embs.clone()
+                m._encoder.latent_pos_enc.pos_embs.mul_(3.0e5 / 0.02)
+            y_big = m(x).clone()
+            assert torch.isfinite(y_big).all(), "deferred guard must have repeated the forward un-folded"
+            with torch.no_grad():
+                m._encoder.latent_pos_enc.pos_embs.copy_(saved)
+            # (b) capture with the guard on
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                for _ in range(2):
+                    m(x)
+            torch.cuda.current_stream().wait_stream(s)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                yg = m(x)
+            g.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(yg, y), "graph replay must reproduce the eager logits"
+            assert int(R.last_range_flag(dev).item()) == 0
+    finally:
+        _policy("fp16x3")
 
 
 @pytest.mark.parametrize("kind", ["dc_offset_30sigma", "outlier_channel_1e4"])

@@ -13,7 +13,6 @@ from perceiverio_pytorch_amd import runtime as R  # noqa: E402
 
 dev = torch.device("cuda:0")
 model, _ = Bn.build_model("imagenet", dev, "fp16")
-R.set_range_check(False)   # (the guard's isfinite().all() is a host sync: not capturable)
 for B in (1, 2, 4, 8):
     x = torch.randn(B, 3, 224, 224, device=dev)
     with torch.inference_mode():
