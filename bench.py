@@ -337,6 +337,71 @@ def _limit_blas_threads(n):
         return contextlib.nullcontext()
 
 
+def main_stub(args):
+    """bench.py's multi-rank control flow on CPU (gloo) around a stand-in model: what the driver's
+    `python -m torch.distributed.run ... bench.py --gpus N` exercises besides the kernels."""
+    import torch
+    from perceiverio_pytorch_amd.dist import all_gather_rows
+    cfg = CONFIGS[args.config]
+    steps = args.steps if args.steps is not None else 3
+    warmup = args.warmup if args.warmup is not None else 1
+    B = args.batch or 4
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+        dist = dist_
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    gen = torch.Generator(device="cpu").manual_seed(1000 + rank)       # per-rank inputs, as make_inputs()
+    x = torch.randn(B, 3, 8, 8, generator=gen)
+    w = torch.randn(3 * 8 * 8, 10, generator=torch.Generator(device="cpu").manual_seed(SEED))   # replicated weights
+
+    def step():
+        out = x.flatten(1) @ w
+        if world > 1:
+            out = all_gather_rows(out)                     # [B * W, 10] on every rank
+        return out
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = step()
+    sync()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    # every rank holds every rank's rows, in rank order
+    ok = tuple(out.shape) == (B * world, 10)
+    if world > 1:
+        mine = x.flatten(1) @ w
+        ok = ok and bool(torch.equal(out[rank * B:(rank + 1) * B], mine))
+    line = {"metric": cfg["metric"], "value": world * B * steps / el, "unit": "samples/s", "n_gpus": world,
+            "steps": steps, "warmup": warmup, "ms_per_step": el / steps * 1e3, "higher_is_better": True,
+            "scaling": cfg["scaling"], "vs_baseline": None, "dtype": "f32", "data": "stub",
+            "config": {"workload": "STUB control-flow rehearsal (CPU, gloo): not a measurement", "batch_per_gpu": B,
+                       "global_batch": world * B, "parallelism": f"dp{world}"},
+            "gather_ok": ok}
+    if world > 1:
+        oks = [None] * world
+        dist.all_gather_object(oks, ok)
+        line["gather_ok"] = all(oks)
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -354,8 +419,14 @@ def main():
     # PIO_BENCH_REHEARSE=1 (1-GPU box): go through the same spawn + multi-rank code with every rank on cuda:0 and the
     # gloo backend (RCCL refuses two ranks on one device) -- a rehearsal of the control flow, not a measurement
     rehearse = os.environ.get("PIO_BENCH_REHEARSE", "0") == "1"
+    # PIO_BENCH_STUB=1 (tests/test_bench_flow.py, no GPU): the SAME control flow -- spawn, rank environment, process
+    # group, per-rank inputs, step + all-gather, barrier-bracketed timed region, MAX over ranks, one JSON line from
+    # rank 0 -- with a stand-in CPU model over gloo.  The line says "data": "stub": it is never a measurement.
+    stub = os.environ.get("PIO_BENCH_STUB", "0") == "1"
     if (args.gpus > 1 or rehearse) and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))                   # (nothing in this process has touched the GPU yet)
+    if stub:
+        return main_stub(args)
 
     import numpy as np
     import torch

@@ -30,22 +30,43 @@ def shard_batch(x: torch.Tensor, rank: Optional[int] = None, world: Optional[int
     return x[lo:hi]
 
 
-def all_gather_rows(local: torch.Tensor, total_rows: Optional[int] = None, group=None) -> torch.Tensor:
-    """Concatenate every rank's [b_r, ...] block along dim 0 in rank order.  Equal shards use one all_gather;
-    ragged shards (total_rows given, not divisible) are padded to the largest shard and trimmed."""
+_gather_buffers = {}
+
+
+def _gather_buffer(shape, dtype, device) -> torch.Tensor:
+    """One preallocated [rows * world, ...] receive buffer per (shape, dtype, device): the per-step all-gather of the
+    logits writes into it directly (all_gather_into_tensor) instead of allocating `world` pieces and concatenating
+    them.  The caller owns the result until its next call with the same shape."""
+    key = (tuple(shape), dtype, str(device))
+    buf = _gather_buffers.get(key)
+    if buf is None:
+        with torch.inference_mode(False):
+            buf = torch.empty(shape, dtype=dtype, device=device)
+        _gather_buffers[key] = buf
+    return buf
+
+
+def all_gather_rows(local: torch.Tensor, total_rows: Optional[int] = None, group=None,
+                    reuse_buffer: bool = True) -> torch.Tensor:
+    """Concatenate every rank's [b_r, ...] block along dim 0 in rank order.  Equal shards are ONE
+    all_gather_into_tensor into a preallocated [b * W, ...] buffer (reuse_buffer: the same tensor is returned by the
+    next call of this shape); ragged shards (total_rows given, not divisible) are padded to the largest shard and
+    trimmed."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return local
     world = dist.get_world_size(group)
     local = local.contiguous()
     if total_rows is None or total_rows % world == 0:
-        out: List[torch.Tensor] = [torch.empty_like(local) for _ in range(world)]
-        dist.all_gather(out, local, group=group)
-        return torch.cat(out, dim=0)
+        shape = (local.shape[0] * world,) + tuple(local.shape[1:])
+        out = _gather_buffer(shape, local.dtype, local.device) if reuse_buffer else \
+            torch.empty(shape, dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(out, local, group=group)
+        return out
     sizes = [shard_bounds(total_rows, r, world) for r in range(world)]
     mx = max(hi - lo for lo, hi in sizes)
     pad = torch.zeros((mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     pad[: local.shape[0]] = local
-    out = [torch.empty_like(pad) for _ in range(world)]
+    out: List[torch.Tensor] = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(out, pad, group=group)
     return torch.cat([o[: hi - lo] for o, (lo, hi) in zip(out, sizes)], dim=0)
 
@@ -81,6 +102,15 @@ def decode_query_sharded(decode, query: torch.Tensor, latents: torch.Tensor,
     """`decode(query_rows, latents, query_mask=rows_of_mask)` on this rank's query rows, then the all-gather along
     the query axis: every rank returns the full [B, Q, C_out].  `decode` is PerceiverDecoder.forward in the product
     path (PerceiverIO.forward(query_shard=...), bench.py --config flow) and any row-independent function in tests."""
+    if world is not None and world > 1:
+        # an explicit shard of a world that does not exist would return a [B, Q/W, C] block that every caller downstream
+        # (restructure, the postprocessors) takes for the full query set: refuse instead of returning wrong output
+        if not dist.is_initialized():
+            raise RuntimeError(f"decode_query_sharded(rank={rank}, world={world}): torch.distributed is not initialised; "
+                               "a query shard can only be completed by the all-gather of an initialised process group")
+        if dist.get_world_size(group) != world:
+            raise RuntimeError(f"decode_query_sharded: world={world} but the process group has "
+                               f"{dist.get_world_size(group)} ranks")
     q_local, m_local = shard_queries(query, rank, world, query_mask)
     y_local = decode(q_local, latents, query_mask=m_local)
     return all_gather_queries(y_local, query.shape[1], group=group)

@@ -104,3 +104,14 @@ def test_query_shard_and_allgather_world2(total_q):
     assert sum(r[1] for r in res) == total_q
     for _, _, out in res:
         assert out.shape == full.shape and np.array_equal(out, full)
+
+
+def test_explicit_query_shard_without_process_group_raises():
+    """decode_query_sharded(rank, world > 1) without an initialised process group must not return a [B, Q/W, C] block
+    that the callers downstream would take for the full query set."""
+    from perceiverio_pytorch_amd.dist import decode_query_sharded
+    query = torch.zeros(1, 8, 6)
+    with pytest.raises(RuntimeError, match="not initialised"):
+        decode_query_sharded(_decode_stub, query, torch.ones(1, 4, 3), None, 0, 2)
+    # world 1 (or unspecified without a group) is the whole query set: fine
+    assert decode_query_sharded(_decode_stub, query, torch.ones(1, 4, 3), None, 0, 1).shape == (1, 8, 6)
