@@ -50,7 +50,11 @@ SEED = 31                    # parameter seed of the committed whole-model golde
 
 # algorithmic GFLOP per sample of the hot path (2*m*n*k per product, reference formulation)
 CONFIGS = {
-    "imagenet": dict(golden="model_classify_conv", parity_golden="model_classify_b4_s31", batch=32, policy="fp16",
+    "imagenet": dict(golden="model_classify_conv", parity_golden="model_classify_b4_s31",
+                     # the gate runs on EVERY B = 4 reference golden (five seeds + natural-image statistics), worst case reported
+                     parity_goldens=["model_classify_b4_s31", "model_classify_b4_s32", "model_classify_b4_s33",
+                                     "model_classify_b4_s34", "model_classify_b4_s35", "model_classify_b4_natural"],
+                     batch=32, policy="fp16",
                      gflop=381.65, scaling="weak",
                      metric="samples/sec PerceiverIO fwd (ImageNet-224, 512x1024 latents, 8 blocks x 6 self-attends)",
                      workload="imagenet224 ClassificationPerceiver (conv+Fourier prep -> encoder 3136x322->512x1024, "
@@ -173,9 +177,25 @@ def parity_check(name, model, params, dev, policy):
     out = {"tol": 1e-3, "golden": f"tests/golden/{gname}.npz (reference fp32 outputs)"}
     with torch.inference_mode():
         if name == "imagenet":
-            y = model(ins[0]).cpu().numpy()
-            rl2, rmax = rel_errors(y, g["out"])
-            out["case"] = "ClassificationPerceiver B=4 (2048 latent rows: same LayerNorm-fold path as the timed batch)"
+            # every B = 4 golden: the parameters of a golden are those of ITS seed (the timed model keeps seed 31's)
+            from cases import gen_state_dict, model_seed
+            per = {}
+            keep = {k: v.clone() for k, v in model.state_dict().items()}
+            for gn in CONFIGS[name]["parity_goldens"]:
+                gg = np.load(os.path.join(ROOT, "tests", "golden", gn + ".npz"))
+                if model_seed(gn) != SEED:
+                    sd = gen_state_dict(spec_of(gg), model_seed(gn))
+                    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+                xi = torch.from_numpy(model_inputs(gn)[0]).to(dev)
+                per[gn] = rel_errors(model(xi).cpu().numpy(), gg["out"])
+            model.load_state_dict(keep, strict=True)
+            worst = max(per, key=lambda k: max(per[k]))
+            rl2, rmax = max(v[0] for v in per.values()), max(v[1] for v in per.values())
+            out["golden"] = "tests/golden/model_classify_b4_*.npz (reference fp32 outputs)"
+            out["per_golden"] = {k: {"relL2": v[0], "max_abs_over_absmax": v[1]} for k, v in per.items()}
+            out["worst"] = worst
+            out["case"] = ("ClassificationPerceiver B=4 (2048 latent rows: same LayerNorm-fold path as the timed batch), "
+                           "5 parameter/input seeds + natural-image statistics; worst case gates")
         elif name == "language":
             y = model(ins[0], ins[1]).cpu().numpy()
             rl2, rmax = rel_errors(y[:, :96], g["out"], g["out_absmax"])

@@ -12,7 +12,7 @@
  *   - every pointer is a DEVICE pointer owned by the caller; compute calls allocate and free nothing and
  *     keep no state between calls => they are thread-safe per (stream, workspace).  The only process-wide
  *     mutable state is opt-in tooling, none of it thread-safe: the per-launch profiler (pio_prof_*) and the
- *     A/B switches pio_ln_fold_enable / pio_gemm_kernel_override / pio_flash_variant_override / pio_set_cu_budget (set them before
+ *     A/B switches pio_ln_fold_enable / pio_gemm_kernel_override / pio_set_cu_budget (set them before
  *     concurrent use).
  *   - scratch memory is caller-provided: query pio_*_workspace_bytes() first.
  *   - tensors at the boundary are float32, last dimension contiguous; batch / row strides are given
@@ -153,7 +153,7 @@ const char *pio_error_string(int code);
 /* classes: 0 gemm_nt_256 (flat 256x256 tiles), 1 batched gemm_nt_128 (materialised attention products),
  *          2 layernorm / cast / row statistics, 3 softmax_rows, 4 pack, 5 fused attention (flash_attn),
  *          6 flat gemm_nt_128 (small / ragged problems), 7 gemm_nt_stream (persistent 256x128 tiles: fp32 + residual
- *          projections outside a folded stack), 8 gemm_nt_wide / gemm_nt_duo (persistent 256x256 four-wave kernel:
+ *          projections outside a folded stack), 8 gemm_nt_wide (persistent 256x256 four-wave kernel:
  *          every weight GEMM of the latent self-attend stack -- q|k|v, out, fc1, fc2 -- and the decoder projections) */
 #define PIO_PROF_CLASSES 9
 /* Start recording a HIP-event pair around every kernel launch (up to max_records launches). */
@@ -172,15 +172,10 @@ int pio_ln_fold_enable(int on);
 /* 0: automatic (default; env PIO_GEMM_TILE gives the initial value), 64: 64x64 tiles of the 128-tile kernel (automatic
  * for problems with fewer than 192 tiles of 128x128: small batches), 128: 128x128 tile, 256: 256x256 tile,
  * 1: persistent 256x128 streaming kernel wherever it is legal, 2: persistent 256x256 four-wave kernel wherever
- * it is legal, 3: the LayerNorm-fold producer on the two-workgroups-per-CU kernel (gemm_nt_duo), 4: the LayerNorm-fold
- * GEMMs on the MFMA 32x32x16 variants of the four-wave kernel (fewer cycles, lower clock: level).  Returns the previous
- * setting. */
+ * it is legal.  Returns the previous setting.  (Experiment kernels that measured level with these -- a two-workgroups-
+ * per-CU fold producer, MFMA 32x32x16 variants of the fold GEMMs, two more fused self-attention kernels -- are not in
+ * this library: tools/experiments, built by `make -C perceiverio_pytorch_amd/csrc experiments`.) */
 int pio_gemm_kernel_override(int which);
-/* Variant of the fused self-attention kernel on its hot shape (128-wide heads, V row-major out of the fused q|k|v GEMM,
- * >= 256 queries): 0 = lock-step waves (default; env PIO_FLASH_VARIANT gives the initial value), 1 = one wave per SIMD
- * with the softmax arithmetic issued in the shadow of the MFMAs, 2 = two staggered wave groups.  Any other value only
- * reads.  Returns the previous setting. */
-int pio_flash_variant_override(int which);
 
 /* --- running on a part of the chip ----------------------------------------------------------------- */
 /* A stream whose kernels run only on the CUs whose bit is set in `mask` (`words` 32-bit words; bit i = CU i / 8 of

@@ -116,10 +116,51 @@ MODEL_CASES = {
     "model_classify_b4_s31": dict(cls="ClassificationPerceiver", kw=dict(prep="FOURIER_POS_CONVNET"), batch=4, pseed=31),
     "model_classify_b4_s32": dict(cls="ClassificationPerceiver", kw=dict(prep="FOURIER_POS_CONVNET"), batch=4, pseed=32),
     "model_classify_b4_s33": dict(cls="ClassificationPerceiver", kw=dict(prep="FOURIER_POS_CONVNET"), batch=4, pseed=33),
+    "model_classify_b4_s34": dict(cls="ClassificationPerceiver", kw=dict(prep="FOURIER_POS_CONVNET"), batch=4, pseed=34),
+    "model_classify_b4_s35": dict(cls="ClassificationPerceiver", kw=dict(prep="FOURIER_POS_CONVNET"), batch=4, pseed=35),
+    # the same path on NON-Gaussian inputs: synthetic images with natural-image statistics (1/f amplitude spectrum,
+    # piecewise-constant regions with sharp edges, sparse saturated highlights / shadows -- heavy-tailed after the
+    # ImageNet mean / std normalisation of example_img_classify.py:58-60), parameter seed 36
+    "model_classify_b4_natural": dict(cls="ClassificationPerceiver", kw=dict(prep="FOURIER_POS_CONVNET"), batch=4,
+                                      pseed=36, inputs="natural"),
     # full-size multimodal auto-encoder (BASELINE config 5): 16 x 224 x 224 video + 30720 audio samples + label,
     # M = 52 097 x 704, 784 x 512 latents; output chunks 0 and 127 of n_chunks = 128 (6272 + 15 + 1 queries each)
     "model_multimodal_full": dict(cls="MultiModalPerceiver", kw=dict(), batch=1, chunks=(0, 127), n_chunks=128),
 }
+
+
+def natural_images(name, B, seed, hw=(224, 224)):
+    """Synthetic [B,3,H,W] images with natural-image statistics, ImageNet-normalised: a 1/f field per channel (strongly
+    correlated across channels) squashed to [0,1], overlaid with piecewise-constant rectangles (sharp edges) and a few
+    saturated highlights / shadows, then (x - mean) / std with the ImageNet constants -- a heavy-tailed, spatially
+    correlated, non-zero-mean input, unlike the N(0,1) pixels of the other cases."""
+    rng = O._rng_for(name + "natural", seed)
+    H, W = hw
+    fy = np.fft.fftfreq(H)[:, None]
+    fx = np.fft.fftfreq(W)[None, :]
+    amp = 1.0 / np.maximum(np.sqrt(fx * fx + fy * fy), 1.0 / max(H, W))
+    mean = np.array([0.485, 0.456, 0.406], dtype=np.float64)
+    std = np.array([0.229, 0.224, 0.225], dtype=np.float64)
+    out = np.empty((B, 3, H, W), dtype=np.float32)
+    for b in range(B):
+        base = np.fft.ifft2(amp * np.fft.fft2(rng.standard_normal((H, W)))).real
+        img = np.empty((3, H, W))
+        for ch in range(3):
+            own = np.fft.ifft2(amp * np.fft.fft2(rng.standard_normal((H, W)))).real
+            f = 0.8 * base + 0.2 * own
+            f = (f - f.mean()) / (f.std() + 1e-12)
+            img[ch] = 1.0 / (1.0 + np.exp(-1.5 * f + rng.normal(0, 0.5)))            # [0,1], exposure varies
+        for _ in range(int(rng.integers(4, 10))):                                      # objects: flat regions, sharp edges
+            y0, x0 = int(rng.integers(0, H - 8)), int(rng.integers(0, W - 8))
+            h, w = int(rng.integers(8, H // 2)), int(rng.integers(8, W // 2))
+            img[:, y0:y0 + h, x0:x0 + w] = 0.6 * img[:, y0:y0 + h, x0:x0 + w] + 0.4 * rng.random(3)[:, None, None]
+        for _ in range(int(rng.integers(2, 6))):                                       # saturated highlights / shadows
+            y0, x0 = int(rng.integers(0, H - 4)), int(rng.integers(0, W - 4))
+            h, w = int(rng.integers(2, 24)), int(rng.integers(2, 24))
+            img[:, y0:y0 + h, x0:x0 + w] = float(rng.integers(0, 2))
+        img = np.clip(img + 0.02 * rng.standard_normal(img.shape), 0.0, 1.0)           # sensor noise, clipped
+        out[b] = ((img - mean[:, None, None]) / std[:, None, None]).astype(np.float32)
+    return out
 
 
 def model_seed(name):
@@ -132,6 +173,8 @@ def model_inputs(name, seed=None):
     B = c["batch"]
     seed = model_seed(name) if seed is None else seed
     if c["cls"] == "ClassificationPerceiver":
+        if c.get("inputs") == "natural":
+            return [natural_images(name, B, seed)]
         return [_rand(name + "img", (B, 3, 224, 224), seed)]
     if c["cls"] == "LanguagePerceiver":
         rng = np.random.default_rng(seed)

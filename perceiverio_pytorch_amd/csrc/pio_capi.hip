@@ -130,7 +130,6 @@ const char *pio_error_string(int code) {
 int32_t pio_pad8(int32_t c) { return pad8(c); }
 
 int pio_gemm_kernel_override(int which) { return gemm_kernel_override(which); }
-int pio_flash_variant_override(int which) { return flash_variant_override(which); }
 
 size_t pio_packed_weight_bytes(int32_t out, int32_t in, int32_t row_heads, int32_t col_heads) {
     if (out <= 0 || in <= 0 || row_heads <= 0 || col_heads <= 0 || out % row_heads || in % col_heads) return 0;

@@ -351,7 +351,11 @@ int gemm_nt_launch(const pio_gemm_t &g, hipStream_t s) {
             return (e && atoi(e) == 0) ? 0 : 1;
         }();
         p.staged_epi = staged;
-        p.mf32 = gemm_kernel_choice() == 4 ? 1 : 0;
+#ifdef PIO_EXPERIMENTS
+        p.mf32 = gemm_kernel_choice() == 4 ? 1 : 0;   // (experiments build: the MFMA 32x32x16 variants of the fold GEMMs)
+#else
+        p.mf32 = 0;
+#endif
     }
     if (g.b_lo_n0 && (!g.B_lo || g.A_lo)) return PIO_E_ARG;
     p.n_store = g.n_store > g.N ? g.n_store : g.N;
@@ -406,8 +410,8 @@ int gemm_nt_launch(const pio_gemm_t &g, hipStream_t s) {
             if (forced == 1 || forced == 128 || forced == 256) wide = false;
             const bool fold = p.X16 || p.row_part || p.ln_part || p.ln_c || p.X16_lo || p.R16_hi || p.R16_lo;
             if (fold) {
-                // the producer with 16-bit pairs in and out: two half-height workgroups per CU (override 3 / env
-                // PIO_GEMM_DUO=1), else the wide kernel
+#ifdef PIO_EXPERIMENTS
+                // (experiments build) the producer on two half-height workgroups per CU: override 3 / env PIO_GEMM_DUO=1
                 static const bool duo_env = [] {
                     const char *e = getenv("PIO_GEMM_DUO");
                     return e && atoi(e) != 0;
@@ -418,6 +422,7 @@ int gemm_nt_launch(const pio_gemm_t &g, hipStream_t s) {
                     gemm_duo_launch(p, g.dtype, s);
                     return launch_status();
                 }
+#endif
                 if (!gemm_wide_ok(p, g.batch)) return PIO_E_SHAPE;
                 wide = true;
             }

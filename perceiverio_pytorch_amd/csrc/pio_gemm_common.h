@@ -9,7 +9,7 @@ struct GemmParams {
     int64_t dA1, dB1, dA2, dB2;  // element offsets of the pass-1 / pass-2 operands relative to A / B
     int npass;                   // 1..3 K sweeps accumulating into the same registers
     int staged_epi;              // (gemm_nt_wide, LayerNorm-fold producer) 1: LDS-staged, row-coalesced epilogue
-    int mf32;                    // (gemm_nt_wide, fold GEMMs) 1: the MFMA 32x32x16 variants where legal (override 4)
+    int mf32;                    // (experiments build only) gemm_nt_wide fold GEMMs on the MFMA 32x32x16 variants
     int lo_n0;                   // (gemm_nt_wide only) B_lo exists for columns >= lo_n0 (multiple of 256); 0 = all
     void *C, *C_lo;
     int M, N, K;
@@ -163,8 +163,10 @@ void gemm_stream_launch(const GemmParams &p, int dtype, int batch, hipStream_t s
 bool gemm_wide_ok(const GemmParams &p, int batch);
 void gemm_wide_launch(const GemmParams &p, int dtype, hipStream_t s);
 
-// the LayerNorm fold's producer with two 128x256-tile workgroups per CU (pio_gemm_duo.hip)
+#ifdef PIO_EXPERIMENTS
+// the LayerNorm fold's producer with two 128x256-tile workgroups per CU (tools/experiments/pio_gemm_duo.hip)
 bool gemm_duo_ok(const GemmParams &p, int batch);
 void gemm_duo_launch(const GemmParams &p, int dtype, hipStream_t s);
+#endif
 
 }  // namespace pio

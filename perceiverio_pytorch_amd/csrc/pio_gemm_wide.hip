@@ -995,11 +995,9 @@ void gemm_wide_launch(const GemmParams &p, int dtype, hipStream_t s) {
     dim3 grid((unsigned)G, 1, 1), block(256, 1, 1);
 #define PIO_WK(DTV, ACT, OUT, R, LNF) \
     hipLaunchKernelGGL((gemm_nt_wide<DTV, ACT, OUT, R, LNF>), grid, block, 0, s, p, tiles_m, tiles_n)
-    // MFMA 32x32x16 variants: the LayerNorm fold's consumer and its staged producer on whole tiles (one tile per
-    // workgroup for the producer: its staged epilogue is the last tile's).  An experiment, off unless PIO_WIDE_MF32=1 / pio_gemm_kernel_override(4):
-    // the main loop needs 7 % fewer cycles (the longer MFMA hides the LDS-DMA issue stalls better) and the chip answers
-    // with a 5 % lower clock -- 74 956 cycles at 1.45 GHz against 78 304 at 1.53 GHz for a producer launch back to back,
-    // 112 against 107 us for q|k|v in the model: the path is power-limited, not issue-limited.
+    // MFMA 32x32x16 variants of the fold GEMMs (template parameter MF): an experiment that measured level -- 7 % fewer
+    // cycles, 5 % less clock (DESIGN_LOG.md) -- instantiated in the experiments build only (-DPIO_EXPERIMENTS).
+#ifdef PIO_EXPERIMENTS
     static const bool mf32_on = [] {
         const char *e = getenv("PIO_WIDE_MF32");
         return e && atoi(e) != 0;
@@ -1011,6 +1009,10 @@ void gemm_wide_launch(const GemmParams &p, int dtype, hipStream_t s) {
                          (int64_t)tiles_m * tiles_n <= G;
 #define PIO_WKM(DTV, ACT, OUT, R, LNF) \
     hipLaunchKernelGGL((gemm_nt_wide<DTV, ACT, OUT, R, LNF, 1>), grid, block, 0, s, p, tiles_m, tiles_n)
+#else
+    const bool mf_cons = false, mf_prod = false;
+#define PIO_WKM(DTV, ACT, OUT, R, LNF) ((void)0)
+#endif
 #define PIO_WS(DTV)                                                  \
     do {                                                             \
         if (mf_prod) PIO_WKM(DTV, 0, 2, 2, 1);                       \

@@ -107,7 +107,6 @@ int softmax_rows_launch(const float *S, int64_t lds, void *P, void *P_lo, int64_
                         float scale, const uint8_t *kv_mask, const uint8_t *q_mask, const uint8_t *full_mask,
                         const float *bias, int dtype, float *probs_out, hipStream_t s);
 bool flash_supported(int dkp, int dvp);
-int flash_variant_override(int which);  // see pio_flash.hip
 int flash_attention_launch(int dtype, int dkp, int dvp, int dk_logical, const void *Q, const void *K, const void *VT,
                            void *O, int B, int H, int Tq, int Tk, int64_t ldq, int64_t ldk, int64_t ldvt, int64_t ldo,
                            int64_t sQb, int64_t sKb, int64_t sVb, int64_t sOb, bool v_rowmajor, hipStream_t s);

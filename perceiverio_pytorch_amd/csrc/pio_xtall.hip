@@ -189,8 +189,10 @@ __global__ __launch_bounds__(256, 1) void xattn_tall_kernel(const XtallParams p)
     auto issue_piece = [&](auto PI) {
         constexpr int i = decltype(PI)::value;
         if constexpr (i < 8) {
-            const uint32_t o = i_b ? voff[i] + (uint32_t)i_vadj : koff[i];
-            xt_dma16(i_src0 + 2 * (uint64_t)o, i_dst + i * i_step);
+            // (signed: the column correction of a chunk past the row pitch is negative and may exceed a small row offset --
+            //  the chunk's base pointer, which already carries cb * 64, makes up for it)
+            const int32_t o = i_b ? (int32_t)voff[i] + i_vadj : (int32_t)koff[i];
+            xt_dma16(i_src0 + 2 * (int64_t)o, i_dst + i * i_step);
         } else {
             uint32_t &o = qoff[i & 1];
             asm volatile("" : "+v"(o));

@@ -685,7 +685,7 @@ def test_gemm_layernorm_fold(dev, M, N2, act, dt):
     gq.X16_lo, gq.R16_hi, gq.R16_lo = Xl.data_ptr(), Rhi.data_ptr(), Rlo.data_ptr()
     xref2 = A.double() @ W1.double().T + b1.double() + Rhi.double() + Rlo.double()
     pair_tol = 2e-6 if dt == "f16" else 4e-5
-    for kernel in (0, 3):  # 0: gemm_nt_wide, 3: gemm_nt_duo (two half-height workgroups per CU)
+    for kernel in (0,):  # (the two-workgroups-per-CU producer, override 3, lives in tools/experiments)
         Xh.fill_(float("nan")); Xl.fill_(float("nan")); part2.fill_(float("nan"))
         prev = lib.pio_gemm_kernel_override(kernel)
         try:
@@ -724,7 +724,11 @@ def test_gemm_layernorm_fold(dev, M, N2, act, dt):
     got = Y.double()
     assert torch.isfinite(got).all()
     err = ((got - ref).abs().max() / ref.abs().max()).item()
-    assert err <= (3e-3 if dt == "f16" else 2e-2), f"folded LayerNorm GEMM M={M} N={N2} act={act} {dt}: {err:.3e}"
+    rl2 = ((got - ref).norm() / ref.norm()).item()
+    print(f"folded LayerNorm GEMM M={M} N={N2} act={act} {dt}: relL2={rl2:.3e} max/absmax={err:.3e}")
+    # fp16 at the north_star's bar against the exact float64 result (measured 3e-4 / 4e-4); bf16 is the range fallback,
+    # not a parity policy (8-bit mantissa: 2.4e-3 / 3.2e-3)
+    assert max(err, rl2) <= (TOL if dt == "f16" else 5e-3), f"folded LayerNorm GEMM M={M} N={N2} act={act} {dt}: {rl2:.3e} / {err:.3e}"
     # the same roundings in fp64: only the accumulation order and the 16-bit output rounding remain
     mu = xd.mean(-1, keepdim=True)
     rs = 1.0 / torch.sqrt(xd.var(-1, unbiased=False, keepdim=True) + 1e-5)
@@ -787,37 +791,11 @@ def test_self_attention_layernorm_fold(dev, policy):
     e_fold = ((y_fold - ref).abs().max() / scale).item()
     e_plain = ((y_plain - ref).abs().max() / scale).item()
     assert not torch.equal(y_fold, y_plain), "the fold did not run (identical results)"
-    tol = 2e-3 if policy == "fp16" else 1.5e-2
+    print(f"SA block {policy}: fold relL2={((y_fold - ref).norm() / ref.norm()).item():.3e} max={e_fold:.3e} | "
+          f"plain relL2={((y_plain - ref).norm() / ref.norm()).item():.3e} max={e_plain:.3e}")
+    tol = TOL if policy == "fp16" else 3e-3     # (measured: fp16 1.8e-4, bf16 -- range fallback, not a parity policy -- 1.4e-3)
     assert e_fold <= tol, f"folded block {policy}: {e_fold:.3e} (unfolded {e_plain:.3e})"
     assert e_fold <= 1.5 * e_plain + 2e-4, f"folded block {policy}: {e_fold:.3e} vs unfolded {e_plain:.3e}"
-
-
-def test_model_layernorm_fold_b4(dev):
-    """Full ClassificationPerceiver at B = 4 (2048 latent rows: the fold is taken, with the row statistics carried from
-    block to block), policy fp16: folded vs unfolded logits against the fp16x3 (float32-grade) run of the same model."""
-    import os as _os
-    import sys as _sys
-    _sys.path.insert(0, _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), ".."))
-    import bench as Bn
-    from perceiverio_pytorch_amd import _lib as L
-    lib = L.lib()
-    model, _ = Bn.build_model("imagenet", dev, "fp16")
-    x = torch.randn(4, 3, 224, 224, generator=torch.Generator().manual_seed(11)).to(dev)
-    prev = lib.pio_ln_fold_enable(1)
-    try:
-        with torch.inference_mode():
-            y_fold = model(x).double()
-            lib.pio_ln_fold_enable(0)
-            y_plain = model(x).double()
-            model.precision_policy = "fp16x3"
-            y_ref = model(x).double()
-    finally:
-        lib.pio_ln_fold_enable(prev)
-    rel = lambda a, b: ((a - b).norm() / b.norm()).item()  # noqa: E731
-    e_fold, e_plain = rel(y_fold, y_ref), rel(y_plain, y_ref)
-    assert not torch.equal(y_fold, y_plain), "the fold did not run (identical results)"
-    assert e_fold <= 1e-3, f"folded model relL2 {e_fold:.3e} (unfolded {e_plain:.3e})"
-    assert e_fold <= 1.5 * e_plain + 1e-4, f"folded model relL2 {e_fold:.3e} vs unfolded {e_plain:.3e}"
 
 
 def test_backward_through_hip_modules_raises(dev):
@@ -913,6 +891,29 @@ def _attention_vector_masks(m, xq, xkv, kv_mask, q_mask, dev):
     return out
 
 
+def _attention_vector_masks_kv(m, xq, xk, xv, kv_mask, q_mask, dev):
+    """as _attention_vector_masks, with separate key and value inputs"""
+    import perceiverio_pytorch_amd as P
+    from perceiverio_pytorch_amd import _lib as L, runtime as R
+    lib = P.lib()
+    d = m._desc()
+    B, Tq, Tk = xq.shape[0], xq.shape[1], xk.shape[1]
+    out = torch.empty((B, Tq, m.final.out_features), dtype=torch.float32, device=dev)
+    ws = R.workspace(dev, lib.pio_attention_workspace_bytes(d, B, Tq, Tk))
+    keep = []
+    kp = qp = None
+    if kv_mask is not None:
+        keep.append(_t(kv_mask, dev).view(torch.uint8))
+        kp = keep[-1].data_ptr()
+    if q_mask is not None:
+        keep.append(_t(q_mask, dev).view(torch.uint8))
+        qp = keep[-1].data_ptr()
+    L.check(lib.pio_attention_fwd(d, R.tensor3(xq), R.tensor3(xk), R.tensor3(xv), kp, qp, None, None,
+                                  out.data_ptr(), None, ws.data_ptr(), ws.numel(), R.stream_ptr(dev)), "pio_attention_fwd")
+    torch.cuda.synchronize()
+    return out
+
+
 @pytest.mark.parametrize("policy", ["fp16", "fp16x2w", "bf16", "fp16x3f"])
 @pytest.mark.parametrize("case", XATTN_CASES)
 def test_fused_cross_attention_vs_oracle(dev, case, policy):
@@ -965,6 +966,62 @@ def test_fused_cross_attention_vs_oracle(dev, case, policy):
     full = _t(mask3 if mask3 is not None else np.ones((B, Tq, Tk), bool), dev)
     ym = m(xq_t, _t(xkv, dev), _t(xkv, dev), attention_mask=full)
     _assert_close(y, ym.detach().cpu().numpy(), tol, what=f"fused vs materialised {case} {policy}")
+
+
+# The fused attention KERNELS alone, at the widths of the shipped models, against the float64 oracle at the north_star's
+# 1e-3: the projections around the core are identities on fp16-exact inputs (q = xq, k = xk, v = xv, out = core output),
+# so nothing but the kernel's own arithmetic (Q K^T in fp32, softmax, P rounded to 16 bits, P V in fp32, one 16-bit
+# rounding of the output) separates the result from transformer_primitives.py:138-175 computed in float64.
+KERNEL_CASES = [
+    # heads, dk, dv, B, Tq, Tk, mask kind, kernel
+    (1, 328, 328, 2, 512, 3136, "key", "xattn<352,192> (ImageNet / flow encoder, 322 padded to 328)"),
+    (1, 512, 512, 1, 1024, 784, "query", "xattn<512,256> (multimodal / flow decoder)"),
+    (1, 704, 704, 1, 784, 4096, None, "xattn<704,256> (multimodal encoder, key split)"),
+    (8, 32, 160, 2, 256, 2048, "key", "xattn<32,160> (language encoder)"),
+    (8, 32, 96, 2, 2048, 256, "query", "xattn<32,96> (language decoder)"),
+    (1, 1024, 1024, 2, 1000, 512, None, "xattn_tall (ImageNet decoder)"),
+    (8, 128, 128, 4, 512, 512, None, "flash_attn<128,128> (ImageNet latent self-attention)"),
+    (16, 32, 32, 1, 2048, 2048, None, "flash_attn<32,32> (flow latent self-attention)"),
+    (8, 64, 64, 1, 784, 784, None, "flash_attn<64,64> (multimodal latent self-attention)"),
+]
+
+
+@pytest.mark.parametrize("case", KERNEL_CASES, ids=[c[-1].split(" ")[0] for c in KERNEL_CASES])
+def test_fused_attention_kernels_at_shipped_widths_vs_oracle(dev, case):
+    from perceiverio_pytorch_amd.transformer_primitives import Attention
+    H, dk, dv, B, Tq, Tk, mk, what = case
+    rng = np.random.default_rng(dk * 7 + Tk)
+    f16 = lambda a: a.astype(np.float16).astype(np.float32)  # noqa: E731  (fp16-exact inputs: the identity projections are exact)
+    xq = f16(rng.standard_normal((B, Tq, H * dk)))
+    xk = f16(rng.standard_normal((B, Tk, H * dk)))
+    xv = f16(rng.standard_normal((B, Tk, H * dv)))
+    qm = km = None
+    if mk == "key":
+        km = rng.random((B, Tk)) > 0.3
+        km[:, 0] = True
+    elif mk == "query":
+        qm = rng.random((B, Tq)) > 0.3
+    m = Attention(H * dk, H * dk, H * dv, num_heads=H, qk_out_channels=H * dk, v_out_channels=H * dv,
+                  output_channels=H * dv)
+    with torch.no_grad():
+        for lin, n in ((m.proj_q, H * dk), (m.proj_k, H * dk), (m.proj_v, H * dv), (m.final, H * dv)):
+            lin.weight.copy_(torch.eye(n))
+            lin.bias.zero_()
+    m = m.to(dev).eval()
+    p64 = {k: v.detach().cpu().numpy().astype(np.float64) for k, v in m.state_dict().items()}
+    mask3 = None
+    if mk is not None:
+        mask3 = O.make_cross_attention_mask(qm if qm is not None else np.ones((B, Tq), bool),
+                                            km if km is not None else np.ones((B, Tk), bool))
+    ref = O.attention(p64, xq.astype(np.float64), xk.astype(np.float64), xv.astype(np.float64), H, mask3)
+    _policy("fp16")
+    try:
+        y = _attention_vector_masks_kv(m, _t(xq, dev), _t(xk, dev), _t(xv, dev), km, qm, dev)
+    finally:
+        _policy("fp16x3")
+    rl2, rmax = _errs(y, ref)
+    print(f"{what}: relL2={rl2:.3e} max/absmax={rmax:.3e}")
+    assert rl2 <= TOL and rmax <= TOL, f"{what}: relL2={rl2:.3e} max/absmax={rmax:.3e}"
 
 
 # ----------------------------------------------------------------------------------------------------
@@ -1210,58 +1267,3 @@ def test_conv_downsample_fused_tail_matches_torch_ops(dev, shape, channels, laye
     assert (net.forward_tokens(x) is None) == bn          # training-mode BatchNorm is not folded
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("policy", ["fp16", "bf16"])
-@pytest.mark.parametrize("variant", [1, 2])
-@pytest.mark.parametrize("shape", [(2, 256), (3, 512), (2, 1024), (2, 777), (16, 640)])
-def test_self_attention_kernel_variants_agree(dev, variant, shape, policy):
-    """pio_flash_variant_override: the one-wave-per-SIMD pipelined kernel (1) and the staggered-groups kernel (2) against
-    the default lock-step kernel (0) on the hot shape (1024-channel SelfAttention block, 8 heads of 128, V row-major):
-    same operands, same P rounding (16 bit), different summation order / softmax reference point -> a few 1e-4 of the
-    output scale.  Shapes a variant does not take (odd tile counts, ragged key tails) fall back to variant 0: equal."""
-    import perceiverio_pytorch_amd as P
-    from perceiverio_pytorch_amd import _lib as L
-    from perceiverio_pytorch_amd.transformer_primitives import SelfAttention
-    lib = L.lib()
-    _policy(policy)
-    B, T = shape
-    torch.manual_seed(T)
-    m = SelfAttention(1024, widening_factor=1, num_heads=8).to(dev).eval()
-    x = torch.randn(B, T, 1024, device=dev) * 1.5 + 0.2
-    prev = lib.pio_flash_variant_override(0)
-    try:
-        y0 = m(x).double()
-        assert lib.pio_flash_variant_override(variant) == 0
-        y1 = m(x).double()
-    finally:
-        lib.pio_flash_variant_override(prev)
-    assert lib.pio_flash_variant_override(7) == prev and lib.pio_flash_variant_override(-2) == prev  # others only read
-    scale = y0.abs().max()
-    k = 1.0 if policy == "fp16" else 8.0       # bf16 P: 8 mantissa bits instead of 11
-    assert ((y1 - y0).abs().max() / scale).item() <= 3e-4 * k, f"variant {variant} {shape}"
-    assert ((y1 - y0).norm() / y0.norm()).item() <= 2e-4 * k
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("policy", ["fp16", "fp16x2w"])
-def test_fold_gemms_on_32x32_mfma_agree(dev, policy):
-    """pio_gemm_kernel_override(4): the LayerNorm fold's consumer (q|k|v, fc1 + GELU) and staged producer (out, fc2) on
-    the MFMA 32x32x16 variants of gemm_nt_wide against the default 16x16x32 ones -- same operands, same K order per
-    accumulator, different accumulator / epilogue lane mapping: agreement to fp32 rounding of the epilogues."""
-    from perceiverio_pytorch_amd import _lib as L
-    from perceiverio_pytorch_amd.transformer_primitives import SelfAttention
-    lib = L.lib()
-    _policy(policy)
-    torch.manual_seed(9)
-    m = SelfAttention(1024, widening_factor=1, num_heads=8).to(dev).eval()
-    x = torch.randn(8, 512, 1024, device=dev) * 1.5 + 0.2
-    prev = lib.pio_gemm_kernel_override(0)
-    try:
-        y0 = m(x).double()
-        lib.pio_gemm_kernel_override(4)
-        y1 = m(x).double()
-    finally:
-        lib.pio_gemm_kernel_override(prev)
-    assert not torch.equal(y0, y1), "override 4 did not change the kernels"
-    assert ((y1 - y0).abs().max() / y0.abs().max()).item() <= 2e-4
-    assert ((y1 - y0).norm() / y0.norm()).item() <= 5e-5

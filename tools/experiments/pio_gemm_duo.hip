@@ -17,7 +17,7 @@
 // Reference semantics: x + Linear(...) of transformer_primitives.py:290-292.
 #include <type_traits>
 
-#include "pio_gemm_common.h"
+#include "../../perceiverio_pytorch_amd/csrc/pio_gemm_common.h"
 
 namespace pio {
 

@@ -19,9 +19,9 @@ for B, T in [(2, int(t)) for t in sys.argv[1:]] or ((4, 512), (2, 777), (32, 512
     ys = []
     with torch.no_grad():
         for v in (0, 1):
-            prev = lib.pio_flash_variant_override(v)
+            prev = lib.pio_debug_flash_variant(v)
             ys.append(m(x).double())
-            lib.pio_flash_variant_override(prev)
+            lib.pio_debug_flash_variant(prev)
     for v in (1,):
         d = (ys[v] - ys[0]).abs()
         print(f"B={B} T={T}: variant {v} vs 0: max |diff| {d.max().item():.3e} (|y| max {ys[0].abs().max().item():.3f}), "

@@ -22,7 +22,7 @@ if "--build" in sys.argv:
     for n in MASKS:
         o = os.path.join(out, f"flash_{n}.o")
         subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950",
-                               "-DPIO_FLASH_STAMPS", f"-DPIO_FLASH_ABL={n}", "-c", os.path.join(src, "pio_flash.hip"),
+                               "-DPIO_FLASH_STAMPS", "-DPIO_EXPERIMENTS", f"-DPIO_FLASH_ABL={n}", "-c", os.path.join(src, "pio_flash.hip"),
                                "-o", o])
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o",
                                os.path.join(out, f"libpio_flash_{n}.so"), o] + objs)
