@@ -404,8 +404,16 @@ int gemm_nt_launch(const pio_gemm_t &g, hipStream_t s) {
         {
             // (With a residual the kernel is legal but not chosen: the 64 MB residual read of a 16384x1024 launch is
             //  exposed in its epilogue -- 49 us against 39 without -- where the streaming kernel hides most of it.)
-            bool wide = g.batch == 1 && g.M >= 2048 && (double)tn256 * 256.0 <= 1.25 * p.n_store &&
-                        (int64_t)tm256 * tn256 >= 256 && (!p.R || wide_residual());
+            // (from 128 tiles on: below one tile per CU the four-wave kernel still beats gemm_nt_256 tile for tile -- the
+            //  language model's 8192 x 1280 projections have 160 -- and with fewer than two 256x128 tiles per CU the
+            //  streaming kernel has nothing to hide a residual epilogue behind, so those come here too)
+            const int64_t t256 = (int64_t)tm256 * tn256;
+            static const int wide_min = [] {
+                const char *e = getenv("PIO_WIDE_MIN_TILES");
+                return e ? atoi(e) : 128;
+            }();
+            bool wide = g.batch == 1 && g.M >= 2048 && (double)tn256 * 256.0 <= 1.25 * p.n_store && t256 >= wide_min &&
+                        (!p.R || wide_residual() || 2 * t256 < 448);
             if (forced == 2) wide = true;
             if (forced == 1 || forced == 128 || forced == 256) wide = false;
             const bool fold = p.X16 || p.row_part || p.ln_part || p.ln_c || p.X16_lo || p.R16_hi || p.R16_lo;

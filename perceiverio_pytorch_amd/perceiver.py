@@ -56,6 +56,9 @@ class PerceiverEncoder(nn.Module):
         """Reference signature (perceiver.py:98).  Extension: `inputs` may be a pair (features [B,M,C1], table [M,C2] or
         [1,M,C2]) standing for their channel-wise concatenation with the table broadcast over the batch -- the
         encoder then never sees a materialised [B,M,C1+C2] array (pio_encoder_fwd_split)."""
+        if R.cpu_plumbing(inputs[0] if isinstance(inputs, (tuple, list)) else inputs, "PerceiverEncoder.forward"):
+            from . import cpu_plumbing as CP
+            return CP.encoder(self, inputs, latents, input_mask)
         inputs_tail = None
         if isinstance(inputs, (tuple, list)):
             inputs, inputs_tail = inputs
@@ -205,6 +208,9 @@ class PerceiverDecoder(nn.Module):
         return self._final_cache[1]
 
     def forward(self, query, latents, *, query_mask=None):
+        if R.cpu_plumbing(query, "PerceiverDecoder.forward"):
+            from . import cpu_plumbing as CP
+            return CP.decoder(self, query, latents, query_mask)
         R.require_device(query, "PerceiverDecoder.forward")
         lib = L.lib()
         q, z = R.as_f32_3d(query), R.as_f32_3d(latents)

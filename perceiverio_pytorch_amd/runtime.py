@@ -156,10 +156,43 @@ def pad8(c: int) -> int:
     return (c + 7) & ~7
 
 
+# ------------------------------------------------------------------------------------------------
+# backend.  "hip" (default): the hot path exists only as gfx950 kernels -- CPU tensors raise.  "torch": the opt-in CPU
+# PLUMBING backend (cpu_plumbing.py) for machines without a GPU (BASELINE config 1) -- CUDA tensors raise.  Nothing ever
+# switches by itself; there is no fallback in either direction.
+# ------------------------------------------------------------------------------------------------
+_backend = os.environ.get("PIO_BACKEND", "hip")
+if _backend not in ("hip", "torch"):
+    raise ValueError(f"PIO_BACKEND={_backend!r}: 'hip' or 'torch'")
+
+
+def set_backend(name: str) -> None:
+    global _backend
+    if name not in ("hip", "torch"):
+        raise ValueError(f"unknown backend {name!r}: 'hip' (MI355X kernels) or 'torch' (opt-in CPU plumbing)")
+    _backend = name
+
+
+def get_backend() -> str:
+    return _backend
+
+
+def cpu_plumbing(t: torch.Tensor, what: str) -> bool:
+    """True when this call runs on the opt-in CPU plumbing backend.  A CUDA tensor under that backend raises: GPU
+    tensors only ever run on the HIP kernels."""
+    if _backend != "torch":
+        return False
+    if t.is_cuda:
+        raise L.PioError(f"{what}: backend 'torch' is the CPU plumbing path and got a {t.device} tensor; GPU tensors run "
+                         "on the HIP kernels only -- set_backend('hip')")
+    return True
+
+
 def require_device(t: torch.Tensor, what: str) -> None:
     if not t.is_cuda:
         raise L.PioError(f"{what}: perceiverio_pytorch_amd computes on an MI355X (HIP) device only; got a "
-                         f"{t.device} tensor. There is no CPU or eager fallback.")
+                         f"{t.device} tensor. There is no CPU or eager fallback (an explicit CPU plumbing backend "
+                         "exists for machines without a GPU: perceiverio_pytorch_amd.set_backend('torch')).")
 
 
 def stream_ptr(device) -> int:

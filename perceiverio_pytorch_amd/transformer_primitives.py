@@ -165,6 +165,9 @@ class Attention(_HipModule):
 
     def forward(self, inputs_q, inputs_k, inputs_v, attention_mask=None, attention_bias=None,
                 return_matrix=False):
+        if R.cpu_plumbing(inputs_q, "Attention.forward"):
+            from . import cpu_plumbing as CP
+            return CP.attention(self, inputs_q, inputs_k, inputs_v, attention_mask, attention_bias, return_matrix)
         R.require_device(inputs_q, "Attention.forward")
         _no_training_dropout(self, self.dropout.p)
         lib = L.lib()
@@ -231,6 +234,9 @@ class MLP(_HipModule):
         return self._cached(R.param_key(*self._params()), self._build_desc)
 
     def forward(self, x):
+        if R.cpu_plumbing(x, "MLP.forward"):
+            from . import cpu_plumbing as CP
+            return CP.mlp(self, x)
         R.require_device(x, "MLP.forward")
         _no_training_dropout(self, self.dropout.p)
         lib = L.lib()
@@ -319,6 +325,12 @@ class SelfAttention(_HipModule):
         return self._cached(R.param_key(*self._params()), self._build_desc)
 
     def forward(self, inputs, *, attention_mask=None, attention_bias=None, return_matrix: bool = False):
+        if R.cpu_plumbing(inputs, "SelfAttention.forward"):
+            from . import cpu_plumbing as CP
+            if self._v_channels != self._in_channels:
+                raise RuntimeError(f"The size of tensor a ({self._in_channels}) must match the size of tensor b "
+                                   f"({self._v_channels}) at non-singleton dimension 2")
+            return CP.self_attention(self, inputs, attention_mask, attention_bias, return_matrix)
         R.require_device(inputs, "SelfAttention.forward")
         _no_training_dropout(self, self.dropout.p, self.attention.dropout.p, self.mlp.dropout.p)
         if self._v_channels != self._in_channels:
@@ -400,6 +412,9 @@ class CrossAttention(_HipModule):
 
     def forward(self, inputs_q, inputs_kv, *, attention_mask=None, attention_bias=None,
                 return_matrix: bool = False):
+        if R.cpu_plumbing(inputs_q, "CrossAttention.forward"):
+            from . import cpu_plumbing as CP
+            return CP.cross_attention(self, inputs_q, inputs_kv, attention_mask, attention_bias, return_matrix)
         R.require_device(inputs_q, "CrossAttention.forward")
         _no_training_dropout(self, self.dropout.p, self.attention.dropout.p, self.mlp.dropout.p)
         lib = L.lib()

@@ -212,3 +212,52 @@ def test_asm_hazard_checker_flags_copies_behind_inline_asm(tmp_path):
     assert rc == 0, out
     rc, out = run(asm("ds_read_b128 v[4:7], v1 offset:0") + "\ts_cbranch_scc1 .LBB0_2\n.LBB0_2:\n\tv_mov_b32_e32 v9, v5\n")
     assert rc == 0, out                       # per basic block only
+
+
+# ---- BASELINE config 1: example_img_classify.py's model on a machine without a GPU -- the OPT-IN CPU plumbing backend
+def test_config1_cpu_plumbing_backend_matches_reference_golden():
+    """ClassificationPerceiver() with generated parameters on CPU tensors under set_backend("torch") against the
+    reference's float32 logits (tests/golden/model_classify_conv.npz, B = 2): 1e-5.  The backend is explicit: the default
+    one still refuses CPU tensors (test_no_cpu_fallback) and nothing from oracle/ is involved in the product path."""
+    import numpy as np
+    import perceiverio_pytorch_amd as P
+    from cases import gen_state_dict, model_inputs
+    from _golden import load
+    from perceiverio_pytorch_amd import models as M
+    g = load("model_classify_conv")
+    spec = [(str(n), tuple(int(d) for d in str(s).split(",") if d != "")) for n, s in zip(g["spec_names"], g["spec_shapes"])]
+    model = M.ClassificationPerceiver()
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in gen_state_dict(spec, 31).items()}, strict=True)
+    model.eval()
+    x = torch.from_numpy(model_inputs("model_classify_conv")[0])
+    assert P.get_backend() == "hip"
+    with pytest.raises(P.PioError, match="set_backend"):
+        with torch.inference_mode():
+            model(x[:1])
+    P.set_backend("torch")
+    try:
+        with torch.inference_mode():
+            y = model(x).numpy()
+    finally:
+        P.set_backend("hip")
+    ref = g["out"]
+    assert y.shape == ref.shape == (2, 1000)
+    d = y.astype(np.float64) - ref.astype(np.float64)
+    rl2 = np.sqrt((d * d).sum()) / np.sqrt((ref.astype(np.float64) ** 2).sum())
+    rmax = np.abs(d).max() / np.abs(ref).max()
+    assert rl2 <= 1e-5 and rmax <= 1e-5, (rl2, rmax)
+
+
+def test_cpu_plumbing_is_not_reachable_from_the_default_backend():
+    """source-level guarantee: the product package never imports oracle/, and cpu_plumbing is only entered through
+    runtime.cpu_plumbing(), which is False unless the backend was switched explicitly."""
+    import os
+    import re
+    import perceiverio_pytorch_amd as P
+    from perceiverio_pytorch_amd import runtime as R
+    assert P.get_backend() == "hip" and R.cpu_plumbing(torch.zeros(1), "x") is False
+    root = os.path.dirname(P.__file__)
+    for fn in os.listdir(root):
+        if fn.endswith(".py"):
+            src = open(os.path.join(root, fn)).read()
+            assert not re.search(r"^\s*(from|import)\s+(oracle|perceiver_oracle|cases)\b", src, re.M), fn

@@ -1267,3 +1267,19 @@ def test_conv_downsample_fused_tail_matches_torch_ops(dev, shape, channels, laye
     assert (net.forward_tokens(x) is None) == bn          # training-mode BatchNorm is not folded
 
 
+
+
+def test_cpu_plumbing_backend_refuses_gpu_tensors(dev):
+    """set_backend("torch") is the CPU plumbing path of BASELINE config 1: a CUDA tensor under it raises instead of
+    silently running eager ops on the GPU (and the default backend is restored untouched)."""
+    import perceiverio_pytorch_amd as P
+    from perceiverio_pytorch_amd.transformer_primitives import MLP as HipMLP
+    m = HipMLP(32, widening_factor=1).to(dev).eval()
+    x = torch.randn(1, 4, 32, device=dev)
+    P.set_backend("torch")
+    try:
+        with pytest.raises(P.PioError, match="CPU plumbing"):
+            m(x)
+    finally:
+        P.set_backend("hip")
+    assert torch.isfinite(m(x)).all()
