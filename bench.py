@@ -73,7 +73,7 @@ CONFIGS = {
                                  num_self_attend_heads=8, encoder_query_residual=True, decoder_heads=8,
                                  decoder_query_residual=False, final_project=False),
                      hot=dict(M=2048, C=768, Q=2048)),
-    "flow": dict(golden="model_flow_full", parity_golden="model_flow_full", batch=1, policy="fp16x2w/fp16x3f", gflop=1885.5,
+    "flow": dict(golden="model_flow_full", parity_golden="model_flow_full", batch=1, policy="fp16/fp16x2af", gflop=1885.5,
                  scaling="strong",
                  metric="samples/sec PerceiverIO fwd (optical flow, 368x496 frame pair, 2048x512 latents, 24 self-attends)",
                  workload="FlowPerceiver: frame pair [1,3,368,496] x2 -> 3x3 patches -> encoder 182528x322->2048x512, "
@@ -83,7 +83,7 @@ CONFIGS = {
                              decoder_query_residual=False, final_project=True),
                  hot=dict(M=182528, C=322, Q=182528)),
     "multimodal": dict(golden="model_multimodal_full", parity_golden="model_multimodal_full", batch=1,
-                       policy="fp16x2w/fp16x3f",
+                       policy="fp16x2w/fp16x2af",
                        gflop=250.1 + 128 * 57.2, scaling="weak",
                        metric="samples/sec PerceiverIO fwd (multimodal autoencode, 16x224x224 video + audio + label, "
                               "784x512 latents, 128 output chunks)",

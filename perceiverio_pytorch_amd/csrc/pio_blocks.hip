@@ -203,7 +203,7 @@ static int check_attention(const pio_attention_t &a) {
     if (a.o.k != a.heads * a.dvp || a.q.k != pad8(a.q_in) || a.k.k != pad8(a.k_in) || a.v.k != pad8(a.v_in))
         return PIO_E_SHAPE;
     if (!a.q.w_hi || !a.k.w_hi || !a.v.w_hi || !a.o.w_hi) return PIO_E_ARG;
-    if (a.act_split && (!a.q.w_lo || !a.k.w_lo || !a.v.w_lo || !a.o.w_lo)) return PIO_E_ARG;
+    // (split ACTIVATIONS do not require split weights: the "x2a" policies run A_hi B^T + A_lo B^T against single weights)
     return PIO_OK;
 }
 
@@ -406,7 +406,6 @@ static int attention_core(const pio_attention_t &a, Pair xq, bool q_bcast, Pair 
 static int mlp_core(const pio_mlp_t &m, Pair x, int64_t rows, Pair h, const Residual *res, float *out,
                     hipStream_t s, const LnFold *fold_in = nullptr, const LnFold *fold_out = nullptr) {
     if (m.fc1.k != pad8(m.in) || m.fc1.n != pad8(m.hidden) || m.fc2.k != m.fc1.n) return PIO_E_SHAPE;
-    if (m.act_split && (!m.fc1.w_lo || !m.fc2.w_lo)) return PIO_E_ARG;
     PIO_TRY(linear_fwd(m.fc1, m.dtype, x, rows, h.hi, h.lo, false, 0, m.fc1.n, 1, nullptr, s, fold_in));
     return linear_fwd(m.fc2, m.dtype, h, rows, out, nullptr, true, m.out, m.out, 0, res, s, fold_out);
 }
@@ -821,7 +820,6 @@ int pio_decoder_fwd(const pio_cross_attention_t *cross, const pio_linear_t *fina
     if (!final_layer) return PIO_OK;
     // perceiver.py:178-179: final nn.Linear on every query row
     if (final_layer->k != pad8(query->C)) return PIO_E_SHAPE;
-    if (cross->mlp.act_split && !final_layer->w_lo) return PIO_E_ARG;
     const pio_tensor3_t ty = {y, (int64_t)Q * query->C, query->C, B, Q, query->C};
     PIO_TRY(cast_pair(ty, nullptr, p.y16, pad8(query->C), cross->attn.dtype, s));
     return linear_fwd(*final_layer, cross->attn.dtype, p.y16, (int64_t)B * Q, out, nullptr, true, final_out, final_out,

@@ -31,8 +31,12 @@ _POLICIES = {"fp16": (L.PIO_DT_F16, 0, False), "fp16x2s": (L.PIO_DT_F16, 1, Fals
              "bf16x3": (L.PIO_DT_BF16, 3, True),
              # x3f: every GEMM with split operands as x3, but the attention core (Q K^T, softmax, P V) single-sweep on
              # the fused kernels (q / k / v / p rounded once; the core's output leaves as a pair): no score matrix
-             "fp16x3f": (L.PIO_DT_F16, 3, True), "bf16x3f": (L.PIO_DT_BF16, 3, True)}
-_FUSED_CORE = {"fp16x3f", "bf16x3f"}
+             "fp16x3f": (L.PIO_DT_F16, 3, True), "bf16x3f": (L.PIO_DT_BF16, 3, True),
+             # x2af: split ACTIVATIONS against single weights (A_hi B^T + A_lo B^T: two sweeps) around a single-sweep
+             # fused attention core -- for decoders whose error is dominated by the rounding of wide-range inputs
+             # (Fourier / position features of dense outputs), at 2/3 of the x3f cost
+             "fp16x2af": (L.PIO_DT_F16, 0, True)}
+_FUSED_CORE = {"fp16x3f", "bf16x3f", "fp16x2af"}
 _policy = os.environ.get("PIO_PRECISION", "fp16x3")
 if _policy not in _POLICIES:
     raise ValueError(f"PIO_PRECISION={_policy!r} not in {sorted(_POLICIES)}")
