@@ -35,8 +35,6 @@
 
 namespace pio {
 
-namespace {
-
 template <int I, int N, class F>
 __device__ __forceinline__ void xt_for(F &&f) {
     if constexpr (I < N) {
@@ -446,8 +444,6 @@ __global__ __launch_bounds__(256, 1) void xattn_tall_kernel(const XtallParams p)
         after_epilogue = true;
     }
 }
-
-}  // namespace
 
 // ---- host side -----------------------------------------------------------------------------------------------------
 bool xtall_supported(int dkp, int dvp, int Tk) {

@@ -798,6 +798,28 @@ def test_self_attention_layernorm_fold(dev, policy):
     assert e_fold <= 1.5 * e_plain + 2e-4, f"folded block {policy}: {e_fold:.3e} vs unfolded {e_plain:.3e}"
 
 
+@pytest.mark.parametrize("shape", [(1, 512), (2, 200), (1, 77)])
+def test_self_attention_small_batch_uses_64_row_tiles(dev, shape):
+    """Small batches of the 1024-channel block (8 heads of 128, fused q|k|v, V row-major): fewer than 128 workgroups of
+    128 query rows -> the 64-row instantiation of flash_attn_kernel (B = 1: 64 workgroups instead of 32).  Against the
+    float64 restatement of the reference's SelfAttention.forward."""
+    from perceiverio_pytorch_amd.transformer_primitives import SelfAttention
+    B, T = shape
+    _policy("fp16")
+    try:
+        torch.manual_seed(B * 1000 + T)
+        m = SelfAttention(1024, widening_factor=1, num_heads=8).to(dev).eval()
+        x = (torch.randn(B, T, 1024) * 1.2 + 0.1).to(dev)
+        with torch.inference_mode():
+            y = m(x).double()
+        ref = _sa_reference64(m, x)
+        rl2 = ((y - ref).norm() / ref.norm()).item()
+        rmax = ((y - ref).abs().max() / ref.abs().max()).item()
+        assert rl2 <= TOL and rmax <= TOL, (shape, rl2, rmax)
+    finally:
+        _policy("fp16x3")
+
+
 def test_backward_through_hip_modules_raises(dev):
     """With autograd recording, the output of a HIP module carries a grad_fn whose backward raises -- a training step
     cannot silently skip the encoder / decoder parameters."""
