@@ -41,9 +41,8 @@ static __device__ __attribute__((aligned(16))) uint32_t g_zero_chunk_f[4] = {0, 
 
 // VROW = true (DV = 128 only): V is consumed ROW-major ([keys][H*dv], the layout a plain projection GEMM writes, so
 // Q | K | V come out of ONE fused GEMM) through transposed LDS reads; VROW = false: V^T [dv][keys] as before.
-// NW = waves per workgroup: 4 (128 query rows, two workgroups per CU), 8 (256 query rows, one workgroup per CU:
-// every staged K / V tile then serves twice the queries, i.e. half the L2 -> LDS traffic per flop) or 2 (64 query rows:
-// small batches, where 128-row workgroups would leave most CUs without one -- B = 1, 8 heads, 512 latents: 32).
+// NW = waves per workgroup: 4 (128 query rows, two workgroups per CU) or 8 (256 query rows, one workgroup per CU:
+// every staged K / V tile then serves twice the queries, i.e. half the L2 -> LDS traffic per flop).
 template <int DT, int DK, int DV, bool VROW, int NW>
 __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void flash_attn_kernel(const FlashParams p) {
     typedef typename Op<DT>::T T;
@@ -347,13 +346,13 @@ int flash_attention_launch(int dtype, int dkp, int dvp, int dk_logical, const vo
     if (((uintptr_t)Q & 15) || ((uintptr_t)K & 15) || ((uintptr_t)VT & 15) || ((uintptr_t)O & 7)) return PIO_E_ALIGN;
     // 256-row workgroups when that still gives every CU a workgroup (row-major-V flagship path only)
     const bool wide = v_rowmajor && Tq >= 256 && (int64_t)B * H * ((Tq + 255) / 256) >= 256;
-    // 64-row workgroups (row-major-V path) when 128-row ones would occupy fewer than half of the CUs
-    const bool narrow = v_rowmajor && !wide && (int64_t)B * H * ((Tq + 127) / 128) < 128;
-    const int nqt = wide ? (Tq + 255) / 256 : (narrow ? (Tq + 63) / 64 : (Tq + 127) / 128);
+    // (64-row workgroups for small batches -- B = 1: 64 workgroups instead of 32 -- were measured in round 3: 4.00 ms
+    //  against 3.82 ms per B = 1 forward; two waves issuing a whole tile's DMA cost more than the idle CUs: not kept)
+    const int nqt = wide ? (Tq + 255) / 256 : (Tq + 127) / 128;
     const int o_rows16 = (ldo % 8 == 0 && sOb % 8 == 0 && ((uintptr_t)O & 15) == 0) ? 1 : 0;
     FlashParams p{Q, K, VT, O, Tq, Tk, H, nqt, ldq, ldk, ldvt, ldo, sQb, sKb, sVb, sOb,
                   1.4426950408889634f / sqrtf((float)dk_logical), o_rows16};
-    dim3 grid((unsigned)(nqt * B * H), 1, 1), block(wide ? 512 : (narrow ? 128 : 256), 1, 1);
+    dim3 grid((unsigned)(nqt * B * H), 1, 1), block(wide ? 512 : 256, 1, 1);
     ProfScope prof(PROF_FLASH, 2.0 * B * H * (double)Tq * Tk * (dkp + dvp),
                    2.0 * B * H * ((double)Tq * (dkp + dvp) + (double)Tk * (dkp + dvp)), s);
 #define PIO_FLASH(DTV, DKV, DVV) hipLaunchKernelGGL((flash_attn_kernel<DTV, DKV, DVV, false, 4>), grid, block, 0, s, p)
@@ -390,9 +389,6 @@ int flash_attention_launch(int dtype, int dkp, int dvp, int dk_logical, const vo
     if (v_rowmajor && wide) {
         if (dtype == PIO_DT_F16) hipLaunchKernelGGL((flash_attn_kernel<PIO_DT_F16, 128, 128, true, 8>), grid, block, 0, s, p);
         else hipLaunchKernelGGL((flash_attn_kernel<PIO_DT_BF16, 128, 128, true, 8>), grid, block, 0, s, p);
-    } else if (v_rowmajor && narrow) {
-        if (dtype == PIO_DT_F16) hipLaunchKernelGGL((flash_attn_kernel<PIO_DT_F16, 128, 128, true, 2>), grid, block, 0, s, p);
-        else hipLaunchKernelGGL((flash_attn_kernel<PIO_DT_BF16, 128, 128, true, 2>), grid, block, 0, s, p);
     } else if (v_rowmajor) {
         if (dtype == PIO_DT_F16) hipLaunchKernelGGL((flash_attn_kernel<PIO_DT_F16, 128, 128, true, 4>), grid, block, 0, s, p);
         else hipLaunchKernelGGL((flash_attn_kernel<PIO_DT_BF16, 128, 128, true, 4>), grid, block, 0, s, p);

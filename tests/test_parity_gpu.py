@@ -799,10 +799,9 @@ def test_self_attention_layernorm_fold(dev, policy):
 
 
 @pytest.mark.parametrize("shape", [(1, 512), (2, 200), (1, 77)])
-def test_self_attention_small_batch_uses_64_row_tiles(dev, shape):
-    """Small batches of the 1024-channel block (8 heads of 128, fused q|k|v, V row-major): fewer than 128 workgroups of
-    128 query rows -> the 64-row instantiation of flash_attn_kernel (B = 1: 64 workgroups instead of 32).  Against the
-    float64 restatement of the reference's SelfAttention.forward."""
+def test_self_attention_small_batch(dev, shape):
+    """Small batches of the 1024-channel block (8 heads of 128, fused q|k|v, V row-major, ragged last query tile) against
+    the float64 restatement of the reference's SelfAttention.forward."""
     from perceiverio_pytorch_amd.transformer_primitives import SelfAttention
     B, T = shape
     _policy("fp16")
