@@ -106,7 +106,8 @@ __global__ __launch_bounds__(256, (DKL <= 128 && DVS <= 160) ? 2 : 1) void xattn
     constexpr int K_PIECES = K_TILE / 1024, V_PIECES = V_TILE / 1024;    // 1-KiB LDS-DMA pieces
     constexpr int KPW = (K_PIECES + 3) / 4, VPW = (V_PIECES + 3) / 4;    // pieces per wave
     constexpr int NQS = DKL / 16, NDT = DVS / 32;
-    constexpr int RING = PIN ? 6 : 4;                                     // fragment sets in flight from LDS
+    constexpr int RING = PIN ? (DVS >= 512 ? 3 : 6) : 4;                  // fragment sets in flight from LDS (the
+                                                                          // 512-row accumulator leaves room for three)
     constexpr int NQ_A = PIN ? ((256 - NDT * 16) / 4 < NQS ? (256 - NDT * 16) / 4 : NQS) : 0;  // Q fragments in AGPRs
     static_assert(DKL % 16 == 0 && DVS % 32 == 0 && K_TILE % 1024 == 0 && V_TILE % 1024 == 0, "tile shapes");
     constexpr int STAGE = K_TILE + V_TILE;
@@ -512,7 +513,7 @@ struct XCfg {
     int dkl, dvs;
 };
 // the kernel instantiations, narrowest first
-constexpr XCfg kCfgs[] = {{32, 96}, {32, 160}, {128, 128}, {352, 192}, {512, 256}, {704, 256}};
+constexpr XCfg kCfgs[] = {{32, 96}, {32, 160}, {128, 128}, {352, 352}, {352, 192}, {512, 512}, {512, 256}, {704, 256}};
 
 const XCfg *xattn_cfg(int dkp, int dvp) {
     for (const XCfg &c : kCfgs) {
@@ -600,7 +601,9 @@ int xattn_launch(int dtype, int dkp, int dvp, int dk_logical, const void *Q, con
         if (c->dkl == 32 && c->dvs == 96) PIO_XA(32, 96);
         else if (c->dkl == 32) PIO_XA(32, 160);
         else if (c->dkl == 128) PIO_XA(128, 128);
+        else if (c->dkl == 352 && c->dvs == 352) PIO_XA(352, 352);
         else if (c->dkl == 352) PIO_XA(352, 192);
+        else if (c->dkl == 512 && c->dvs == 512) PIO_XA(512, 512);
         else if (c->dkl == 512) PIO_XA(512, 256);
         else PIO_XA(704, 256);
 #undef PIO_XA

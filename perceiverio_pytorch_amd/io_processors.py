@@ -328,9 +328,15 @@ class ImagePreprocessor(nn.Module, _PosMixin):
         return self._attach_pos(self._features(inputs), pos)
 
     def forward_split(self, inputs: torch.Tensor):
-        """The same network input as two arrays, (features [B,M,C1], position table [M,C2]), or None when this
-        configuration does not concatenate a batch-invariant position table (see _PosMixin._split_pos)."""
-        return self._split_pos(self._features(inputs))
+        """The same network input as two arrays: ("split", features [B,M,C1], position table [M,C2]); when this
+        configuration does not concatenate a batch-invariant position table (see _PosMixin._split_pos) the ordinary
+        hand-off ("full", inputs_with_pos, inputs_without_pos) built from the SAME features -- the preprocessing network
+        runs once either way (in train mode a second pass would also update the BatchNorm statistics twice)."""
+        feats = self._features(inputs)
+        sp = self._split_pos(feats)
+        if sp is not None:
+            return ("split",) + tuple(sp)
+        return ("full",) + tuple(self._attach_pos(feats, None))
 
 
 class OneHotPreprocessor(nn.Module):

@@ -61,8 +61,11 @@ class _policy_scope:
         self._dec = dec if dec != enc else None
 
     def __enter__(self):
+        # a decoder policy the USER set on the core (model.perceiver.decoder_policy = ...) wins over the decoder half of
+        # the model's "encoder/decoder" policy string; it is restored untouched afterwards either way
         self._saved = self._model.perceiver.decoder_policy
-        self._model.perceiver.decoder_policy = self._dec
+        if self._saved is None:
+            self._model.perceiver.decoder_policy = self._dec
         self._ctx.__enter__()
         return self
 

@@ -435,9 +435,17 @@ class PerceiverIO(nn.Module):
         if type(inputs) is torch.Tensor:
             inputs = {"__default": inputs}
         split = self._split_input(inputs, pos) if self.split_encoder_input else None
-        if split is not None:
+        if split is not None and split[0] == "full":
+            # (the preprocessor could not hand over two arrays: its ordinary output, computed once)
+            x = split[1]
+            sizes, without_pos = {"__default": x.shape[1]}, {"__default": split[2]}
+            latents0 = self._encoder.latents(x)
+            query, query_sizes = self.decoder_query(x, sizes, without_pos, subsampled_points=subsampled_output_points)
+            with R.precision(self.encoder_policy):
+                latents = self._encoder(x, latents0, input_mask=input_mask)
+        elif split is not None:
             # the encoder input as (features, batch-invariant position table): never concatenated / replicated in HBM
-            feats, table = split
+            feats, table = split[1], split[2]
             sizes, without_pos = {"__default": feats.shape[1]}, {"__default": feats}
             latents0 = self._encoder.latents(feats)
             query, query_sizes = self.decoder_query(feats, sizes, without_pos,

@@ -288,12 +288,35 @@ def set_cu_split(on: bool) -> None:
     plain streams: the slices' kernel chains then truly run side by side."""
     global _cu_split
     _cu_split = bool(on)
+    release_side_streams()
+
+
+_masked_handles: list = []      # (device index, hipStream_t) of the CU-masked streams this module created
+
+
+def release_side_streams() -> None:
+    """Forget the cached side streams; CU-masked ones (created through pio_stream_create_cu_mask) are destroyed -- they
+    are raw HIP streams that nothing else owns."""
     _side_streams.clear()
+    if _masked_handles:
+        lib = L.lib()
+        for idx, h in _masked_handles:
+            try:
+                with torch.cuda.device(idx):
+                    torch.cuda.synchronize(idx)
+                    lib.pio_stream_destroy(C.c_void_p(h))
+            except Exception:  # noqa: BLE001  (interpreter shutdown / device gone)
+                pass
+        _masked_handles.clear()
 
 
 def cu_share(n: int) -> int:
-    """CUs per slice when the chip is split `n` ways (MI355X: 256 CUs = 8 XCDs x 32)."""
-    return 256 // n
+    """CUs per slice when the chip is split `n` ways, from the device's own CU count (MI355X: 256 = 8 XCDs x 32)."""
+    try:
+        total = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
+    except Exception:  # noqa: BLE001
+        total = 256
+    return total // n
 
 
 def _masked_streams(device: torch.device, n: int) -> list:
@@ -312,6 +335,7 @@ def _masked_streams(device: torch.device, n: int) -> list:
         with torch.cuda.device(device):
             L.check(lib.pio_stream_create_cu_mask(C.byref(h), words, 8), "pio_stream_create_cu_mask")
         out.append(torch.cuda.ExternalStream(h.value, device=device))
+        _masked_handles.append((device.index if device.index is not None else torch.cuda.current_device(), h.value))
     return out
 
 

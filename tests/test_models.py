@@ -239,7 +239,7 @@ def test_split_encoder_input_is_bit_identical_to_the_concatenated_one():
     model = _load_generated(build(name), g, dev)
     model.precision_policy = "fp16x2w"
     x = torch.from_numpy(model_inputs(name)[0]).to(dev)
-    assert model.perceiver.split_encoder_input and model.perceiver._split_input({"__default": x}, None) is not None
+    assert model.perceiver.split_encoder_input and model.perceiver._split_input({"__default": x}, None)[0] == "split"
     with torch.inference_mode():
         y_split = model(x)
         model.perceiver.split_encoder_input = False
