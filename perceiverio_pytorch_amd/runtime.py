@@ -291,23 +291,15 @@ def set_cu_split(on: bool) -> None:
     release_side_streams()
 
 
-_masked_handles: list = []      # (device index, hipStream_t) of the CU-masked streams this module created
+_masked_cache: Dict[Tuple[int, int], list] = {}    # (device index, n) -> CU-masked streams, created ONCE and reused
 
 
 def release_side_streams() -> None:
-    """Forget the cached side streams; CU-masked ones (created through pio_stream_create_cu_mask) are destroyed -- they
-    are raw HIP streams that nothing else owns."""
+    """Forget the cached side streams.  CU-masked streams (raw HIP streams from pio_stream_create_cu_mask) are NOT
+    destroyed here: tensors that were record_stream()-ed on them keep the handle alive inside PyTorch's caching
+    allocator, and destroying it under the allocator crashes the process.  They are created once per (device, split) and
+    reused by every later toggle instead -- a bounded set, no leak."""
     _side_streams.clear()
-    if _masked_handles:
-        lib = L.lib()
-        for idx, h in _masked_handles:
-            try:
-                with torch.cuda.device(idx):
-                    torch.cuda.synchronize(idx)
-                    lib.pio_stream_destroy(C.c_void_p(h))
-            except Exception:  # noqa: BLE001  (interpreter shutdown / device gone)
-                pass
-        _masked_handles.clear()
 
 
 def cu_share(n: int) -> int:
@@ -335,7 +327,6 @@ def _masked_streams(device: torch.device, n: int) -> list:
         with torch.cuda.device(device):
             L.check(lib.pio_stream_create_cu_mask(C.byref(h), words, 8), "pio_stream_create_cu_mask")
         out.append(torch.cuda.ExternalStream(h.value, device=device))
-        _masked_handles.append((device.index if device.index is not None else torch.cuda.current_device(), h.value))
     return out
 
 
@@ -343,7 +334,10 @@ def side_streams(device: torch.device, n: int) -> list:
     key = (device.index if device.index is not None else torch.cuda.current_device(), n, _cu_split)
     if key not in _side_streams:
         if _cu_split and 32 % n == 0:
-            _side_streams[key] = _masked_streams(device, n)
+            mk = (key[0], n)
+            if mk not in _masked_cache:
+                _masked_cache[mk] = _masked_streams(device, n)
+            _side_streams[key] = _masked_cache[mk]
         else:
             _side_streams[key] = [torch.cuda.Stream(device=device) for _ in range(n)]
     return _side_streams[key]
