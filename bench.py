@@ -188,15 +188,19 @@ def parity_check(name, model, params, dev, policy):
                 if model_seed(gn) != SEED:
                     sd = gen_state_dict(spec_of(gg), model_seed(gn))
                     model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
-                xi = torch.from_numpy(model_inputs(gn)[0]).to(dev)
-                per[gn] = rel_errors(model(xi).cpu().numpy(), gg["out"])
+                # the golden's 4 images three times over: B = 12 is 6144 latent rows, where the LayerNorm fold of the
+                # timed batch engages (pio_ln_fold_enable: automatic from 6144 rows); every copy is held to the golden
+                xi = torch.from_numpy(model_inputs(gn)[0]).to(dev).repeat(3, 1, 1, 1)
+                yi = model(xi).cpu().numpy().reshape(3, *gg["out"].shape)
+                per[gn] = tuple(max(e) for e in zip(*(rel_errors(yc, gg["out"]) for yc in yi)))
             model.load_state_dict(keep, strict=True)
             worst = max(per, key=lambda k: max(per[k]))
             rl2, rmax = max(v[0] for v in per.values()), max(v[1] for v in per.values())
             out["golden"] = "tests/golden/model_classify_b4_*.npz (reference fp32 outputs)"
             out["per_golden"] = {k: {"relL2": v[0], "max_abs_over_absmax": v[1]} for k, v in per.items()}
             out["worst"] = worst
-            out["case"] = ("ClassificationPerceiver B=4 (2048 latent rows: same LayerNorm-fold path as the timed batch), "
+            out["case"] = ("ClassificationPerceiver B=4 goldens x 3 copies (6144 latent rows: same LayerNorm-fold path as the timed "
+                           "batch), "
                            "5 parameter/input seeds + natural-image statistics; worst case gates")
         elif name == "language":
             y = model(ins[0], ins[1]).cpu().numpy()

@@ -164,8 +164,9 @@ int pio_prof_begin(int32_t max_records);
 int pio_prof_end(double *ms, double *flops, double *bytes, int64_t *launches);
 
 /* --- LayerNorm fold of the SelfAttention blocks (pio_ln_fold_t), for tests and A/B benchmarks ------ */
-/* 1: use the fold wherever a block offers it (default; env PIO_LN_FOLD gives the initial value), 0: never.
- * Returns the previous setting. */
+/* 0: never; 1: where it pays (default; env PIO_LN_FOLD gives the initial value) -- blocks of >= 6144 rows (env
+ * PIO_LN_FOLD_MIN_ROWS), below which the un-folded block's smaller GEMM tiles fill the chip better; 2: wherever a
+ * block offers it (>= 2048 rows).  Returns the previous setting. */
 int pio_ln_fold_enable(int on);
 
 /* --- kernel selection of pio_gemm_nt, for tests and A/B benchmarks ------------------------------- */

@@ -473,21 +473,35 @@ struct SelfPlan {
     }
 };
 
-// LayerNorm fold switch (pio_ln_fold_enable; initial value from env PIO_LN_FOLD, default on)
+// LayerNorm fold switch (pio_ln_fold_enable; initial value from env PIO_LN_FOLD, default 1).
+// 0: never, 1: where it pays, 2: wherever a block offers it.  "Where it pays": the fold's GEMMs are the 256 x 256-tile
+// kernel, which needs >= 96 tiles of a 1024-wide output to beat the 128 / 64-tile kernels of the un-folded block --
+// measured on the ImageNet classifier (tools/latency_probe.py, ms per forward, fold on / off): B=4 7.75 / 5.22,
+// B=8 8.12 / 7.64, B=12 10.14 / 10.09, B=16 10.69 / 11.57, B=32 16.62 / 18.24 -- hence 6144 rows (env
+// PIO_LN_FOLD_MIN_ROWS).
 static int &ln_fold_choice() {
     static int choice = [] {
         const char *e = getenv("PIO_LN_FOLD");
-        return e ? (atoi(e) != 0 ? 1 : 0) : 1;
+        const int v = e ? atoi(e) : 1;
+        return v < 0 ? 0 : v > 2 ? 2 : v;
     }();
     return choice;
 }
 int ln_fold_enable(int on) {
     int &c = ln_fold_choice();
     const int prev = c;
-    c = on ? 1 : 0;
+    c = on < 0 ? 0 : on > 2 ? 2 : on;
     return prev;
 }
 bool ln_fold_enabled() { return ln_fold_choice() != 0; }
+static int64_t ln_fold_min_rows() {
+    static const int64_t auto_rows = [] {
+        const char *e = getenv("PIO_LN_FOLD_MIN_ROWS");
+        const long long v = e ? atoll(e) : 6144;
+        return (int64_t)(v < 2048 ? 2048 : v);
+    }();
+    return ln_fold_choice() == 2 ? 2048 : auto_rows;
+}
 
 // Carried from one SelfAttention block to the next inside a stack: the 16-bit copy and the partial sums of the block's
 // INPUT, left in the plan's (x16, part_a) buffers by the previous block's fc2 GEMM.
@@ -511,7 +525,7 @@ static int self_attention_run(const pio_self_attention_t &sa, const pio_tensor3_
     // 256x256-tile kernel to fill the chip, nothing that needs the score matrix
     // (weights may be (hi, lo) pairs -- policies "x2s" / "x2w": the wide kernel runs a second K sweep against the lo
     //  image; of the stacked q|k|v image only the V rows may have one.  Activations single-sweep.)
-    const bool fold = ln_fold_enabled() && p.x16b && x.C == 1024 && rows >= 2048 && x.stride_t == x.C &&
+    const bool fold = ln_fold_enabled() && p.x16b && x.C == 1024 && rows >= ln_fold_min_rows() && x.stride_t == x.C &&
                       (B == 1 || x.stride_b == (int64_t)N * x.C) && !sa.attn.act_split && !sa.mlp.act_split &&
                       sa.attn.qkv.w_hi && (!sa.fold.qkv.w_lo || sa.fold.qkv.lo_row0 == 2 * sa.attn.heads * sa.attn.dkp) &&
                       (!sa.fold.fc1.w_lo || sa.fold.fc1.lo_row0 == 0) &&

@@ -779,7 +779,7 @@ def test_self_attention_layernorm_fold(dev, policy):
     m = m.to(dev).eval()
     x = (torch.randn(4, 512, 1024) * 1.5 + 0.2).to(dev)
     ref = _sa_reference64(m, x)
-    prev = lib.pio_ln_fold_enable(1)
+    prev = lib.pio_ln_fold_enable(2)       # 2048 rows: below the automatic setting's 6144
     try:
         with torch.inference_mode():
             y_fold = m(x).double()
@@ -1066,7 +1066,7 @@ def _fold_stack(dev, scale, offset=0.0, outlier=0.0, policy="fp16"):
     enc = enc.to(dev).eval()
     x = _t(np.random.default_rng(3).standard_normal((4, 96, C_)).astype(np.float32), dev)
     outs = {}
-    prev = lib.pio_ln_fold_enable(1)
+    prev = lib.pio_ln_fold_enable(2)       # 2048 rows: below the automatic setting's 6144
     try:
         _policy(policy)
         outs["fold"] = enc(x, enc.latents(x)).clone()
@@ -1102,6 +1102,11 @@ def test_fold_range_guard_falls_back_on_overflow(dev, policy):
     assert int(R.last_range_flag(dev).item()) == 0
 
 
+def _fold_lib():
+    import perceiverio_pytorch_amd as P
+    return P.lib()
+
+
 def test_range_guard_is_deferred_and_graph_capturable(dev):
     """PerceiverIO.forward resolves the range guard once, after the decoder (no synchronisation between encoder and
     decoder), and the whole module forward -- guard ON -- captures into a HIP graph: during capture nothing is read
@@ -1116,6 +1121,7 @@ def test_range_guard_is_deferred_and_graph_capturable(dev):
                     output_queries=TrainableQuery(output_index_dims=8, num_channels=1024)).to(dev).eval()
     x = torch.randn(4, 96, 64, device=dev)                       # 4 x 512 = 2048 latent rows: the fold is active
     _policy("fp16")
+    prev_fold = _fold_lib().pio_ln_fold_enable(2)                # (forced: automatic starts at 6144 rows)
     try:
         with torch.inference_mode():
             y = m(x).clone()
@@ -1143,6 +1149,7 @@ def test_range_guard_is_deferred_and_graph_capturable(dev):
             assert torch.equal(yg, y), "graph replay must reproduce the eager logits"
             assert int(R.last_range_flag(dev).item()) == 0
     finally:
+        _fold_lib().pio_ln_fold_enable(prev_fold)
         _policy("fp16x3")
 
 

@@ -13,7 +13,7 @@ from perceiverio_pytorch_amd import runtime as R  # noqa: E402
 
 dev = torch.device("cuda:0")
 model, _ = Bn.build_model("imagenet", dev, "fp16")
-for B in (1, 2, 4, 8):
+for B in [int(b) for b in os.environ.get("PIO_PROBE_BATCHES", "1,2,4,8").split(",")]:
     x = torch.randn(B, 3, 224, 224, device=dev)
     with torch.inference_mode():
         for _ in range(3):
