@@ -59,8 +59,8 @@ typedef struct pio_linear_t {
     const void *w_hi;
     const void *w_lo;  /* NULL => single pass */
     const float *bias; /* [n_pad] zero padded, or NULL */
-    int32_t n;         /* padded output features  (multiple of 8)  */
-    int32_t k;         /* padded input features   (multiple of 8)  */
+    int32_t n;         /* padded output features: heads x pio_pad8(head dim); pio_padc(hidden) for MLP.fc1         */
+    int32_t k;         /* padded input features: pio_padc(channels); heads x pio_pad8(dv) for Attention.final      */
     int32_t lo_row0;   /* w_lo holds rows [lo_row0, n) only (a stacked q|k|v image whose v part alone is split);
                           0 = every row.  Must be a multiple of 256; honoured by the wide GEMM kernel only.          */
 } pio_linear_t;
@@ -192,8 +192,11 @@ int pio_stream_destroy(void *stream);
 int pio_set_cu_budget(int32_t n_cu);
 
 /* --- weight packing (one-off, after load_state_dict) ------------------------------------------ */
-/* Round a channel count up to the packing granule (8). */
+/* Round a head dim / key count up to the packing granule (8). */
 int32_t pio_pad8(int32_t c);
+/* Pitch of a CHANNEL axis in the 16-bit operand arrays (= pio_linear_t.k of the layers that read it, and
+ * pio_linear_t.n of MLP.fc1): a multiple of 8; from 512 channels on a multiple of 64 (322 -> 328, 1026 -> 1088). */
+int32_t pio_padc(int32_t c);
 /* Bytes of ONE packed image (hi or lo) for out x in with per-head padding of rows / columns:
  * rows = row_heads groups of (out/row_heads) padded to 8 each; columns likewise. */
 size_t pio_packed_weight_bytes(int32_t out, int32_t in, int32_t row_heads, int32_t col_heads);

@@ -95,6 +95,7 @@ SIGNATURES = {
     "pio_prof_begin": (C.c_int, [_i32]),
     "pio_prof_end": (C.c_int, [P(C.c_double), P(C.c_double), P(C.c_double), P(C.c_int64)]),
     "pio_pad8": (_i32, [_i32]),
+    "pio_padc": (_i32, [_i32]),
     "pio_gemm_kernel_override": (C.c_int, [C.c_int]),
     "pio_ln_fold_enable": (C.c_int, [C.c_int]),
     "pio_stream_create_cu_mask": (C.c_int, [P(_vp), P(C.c_uint32), C.c_uint32]),

@@ -37,6 +37,11 @@ struct Residual {
     int rows_per_batch = 0;
 };
 
+// Row pitch (floats) of an INTERNAL fp32 activation buffer: whole float4 groups, so that a channel count like 1026 or
+// 322 does not force the GEMM epilogues and LayerNorm reads onto 4-byte accesses.  The columns [C, pitch4(C)) hold
+// zeros or stale values and are never read as data.
+static inline int pitch4(int c) { return (c + 3) & ~3; }
+
 static Residual residual_of(const pio_tensor3_t &t) {
     Residual r;
     r.ptr = t.data;
@@ -102,6 +107,11 @@ static int linear_fwd(const pio_linear_t &lin_plain, int dtype, Pair x, int64_t 
     g.C_lo = y_lo;
     g.M = (int)rows;
     g.N = out_f32 ? n_logical : lin.n;
+    // fp32 rows with a rounded-up pitch (pitch4: internal buffers): compute whole float4 groups -- the packed image has
+    // zero rows / zero bias behind the logical ones -- so that every store and residual load is a 16-byte one
+    if (out_f32 && (n_logical & 3) && ldc >= pitch4(n_logical) && lin.n >= pitch4(n_logical) &&
+        !(res && res->ptr && res->ld < pitch4(n_logical)))
+        g.N = pitch4(n_logical);
     g.K = lin.k;
     g.lda = lin.k;
     g.ldb = lin.k;
@@ -200,7 +210,7 @@ static int check_attention(const pio_attention_t &a) {
     if (a.heads <= 0 || a.dk <= 0 || a.dv <= 0) return PIO_E_SHAPE;
     if (a.dkp != pad8(a.dk) || a.dvp != pad8(a.dv)) return PIO_E_SHAPE;
     if (a.q.n != a.heads * a.dkp || a.k.n != a.heads * a.dkp || a.v.n != a.heads * a.dvp) return PIO_E_SHAPE;
-    if (a.o.k != a.heads * a.dvp || a.q.k != pad8(a.q_in) || a.k.k != pad8(a.k_in) || a.v.k != pad8(a.v_in))
+    if (a.o.k != a.heads * a.dvp || a.q.k != padc(a.q_in) || a.k.k != padc(a.k_in) || a.v.k != padc(a.v_in))
         return PIO_E_SHAPE;
     if (!a.q.w_hi || !a.k.w_hi || !a.v.w_hi || !a.o.w_hi) return PIO_E_ARG;
     // (split ACTIVATIONS do not require split weights: the "x2a" policies run A_hi B^T + A_lo B^T against single weights)
@@ -211,7 +221,8 @@ static int attention_core(const pio_attention_t &a, Pair xq, bool q_bcast, Pair 
                           const uint8_t *kv_mask, const uint8_t *q_mask, const uint8_t *full_mask,
                           const float *attention_bias, const Residual *res, float *out, float *probs_out,
                           AttnScratch &w, hipStream_t s, const LnFold *fold_in = nullptr,
-                          const LnFold *fold_out = nullptr) {
+                          const LnFold *fold_out = nullptr, int64_t out_ld = 0) {
+    if (!out_ld) out_ld = a.out;  // row pitch of `out` (>= a.out; an internal buffer may round it up: pitch4)
     PIO_TRY(check_attention(a));
     const int H = a.heads;
     const int64_t hdk = (int64_t)H * a.dkp, ldo = (int64_t)H * a.dvp, tkp = pad8(Tk), tkv = round_up(Tk, 32);
@@ -240,7 +251,7 @@ static int attention_core(const pio_attention_t &a, Pair xq, bool q_bcast, Pair 
             PIO_TRY(flash_attention_launch(a.dtype, 128, 128, a.dk, base, base + hdk * 2, base + 2 * hdk * 2,
                                            w.o16.hi, B, H, Tq, Tk, ld3, ld3, ld3, ldo, (int64_t)Tq * ld3,
                                            (int64_t)Tk * ld3, (int64_t)Tk * ld3, (int64_t)Tq * ldo, true, s));
-            return linear_fwd(a.o, a.dtype, w.o16, (int64_t)B * Tq, out, nullptr, true, a.out, a.out, 0, res, s,
+            return linear_fwd(a.o, a.dtype, w.o16, (int64_t)B * Tq, out, nullptr, true, a.out, out_ld, 0, res, s,
                               fold_out);
         }
         if (fold_in || fold_out) return PIO_E_SHAPE;  // the fold is wired into the fused q|k|v form only
@@ -297,14 +308,14 @@ static int attention_core(const pio_attention_t &a, Pair xq, bool q_bcast, Pair 
         PIO_TRY(flash_attention_launch(a.dtype, a.dkp, a.dvp, a.dk, w.q16.hi, k_hi, w.vt16.hi, w.o16.hi, B, H, Tq,
                                        Tk, ldq, ldq, tkv, ldo, q_bcast ? 0 : (int64_t)Tq * ldq, (int64_t)Tk * ldq,
                                        ldo * tkv, (int64_t)Tq * ldo, false, s));
-        return linear_fwd(a.o, a.dtype, w.o16, (int64_t)B * Tq, out, nullptr, true, a.out, a.out, 0, res, s);
+        return linear_fwd(a.o, a.dtype, w.o16, (int64_t)B * Tq, out, nullptr, true, a.out, out_ld, 0, res, s);
     }
     if (score_free && xattn_supported(a.dkp, a.dvp)) {
         PIO_TRY(xattn_launch(a.dtype, a.dkp, a.dvp, a.dk, w.q16.hi, k_hi, w.vt16.hi, w.o16.hi,
                              single_core ? w.o16.lo : nullptr, B, H, Tq, Tk, ldq, ldq,
                              tkv, ldo, q_bcast ? 0 : (int64_t)Tq * ldq, (int64_t)Tk * ldq, ldo * tkv, (int64_t)Tq * ldo,
                              kv_mask, q_mask, w.xpart, s));
-        return linear_fwd(a.o, a.dtype, w.o16, (int64_t)B * Tq, out, nullptr, true, a.out, a.out, 0, res, s);
+        return linear_fwd(a.o, a.dtype, w.o16, (int64_t)B * Tq, out, nullptr, true, a.out, out_ld, 0, res, s);
     }
     if (score_free && xtall_supported(a.dkp, a.dvp, Tk)) {
         // a head wider than the tiled kernel covers, over at most 512 keys (the ImageNet decoder: 1024 channels x 512
@@ -313,7 +324,7 @@ static int attention_core(const pio_attention_t &a, Pair xq, bool q_bcast, Pair 
                              single_core ? w.o16.lo : nullptr, B, H, Tq, Tk, ldq, ldq, tkv, ldo,
                              q_bcast ? 0 : (int64_t)Tq * ldq, (int64_t)Tk * ldq, ldo * tkv, (int64_t)Tq * ldo, kv_mask,
                              q_mask, w.xpart, s));
-        return linear_fwd(a.o, a.dtype, w.o16, (int64_t)B * Tq, out, nullptr, true, a.out, a.out, 0, res, s);
+        return linear_fwd(a.o, a.dtype, w.o16, (int64_t)B * Tq, out, nullptr, true, a.out, out_ld, 0, res, s);
     }
     if (!w.scores) return PIO_E_WORKSPACE;  // (the plan promised a fused kernel)
     // Materialised path, in passes of (b_chunk samples) x (q_chunk query rows) so that the score matrix held at once
@@ -397,17 +408,19 @@ static int attention_core(const pio_attention_t &a, Pair xq, bool q_bcast, Pair 
         }
     }
     // 7: final projection (+ residual) (transformer_primitives.py:110; SelfAttention :290, CrossAttention :396-399)
-    return linear_fwd(a.o, a.dtype, w.o16, (int64_t)B * Tq, out, nullptr, true, a.out, a.out, 0, res, s);
+    return linear_fwd(a.o, a.dtype, w.o16, (int64_t)B * Tq, out, nullptr, true, a.out, out_ld, 0, res, s);
 }
 
 // ------------------------------------------------------------------------------------------------------
 // MLP core on a 16-bit input
 // ------------------------------------------------------------------------------------------------------
 static int mlp_core(const pio_mlp_t &m, Pair x, int64_t rows, Pair h, const Residual *res, float *out,
-                    hipStream_t s, const LnFold *fold_in = nullptr, const LnFold *fold_out = nullptr) {
-    if (m.fc1.k != pad8(m.in) || m.fc1.n != pad8(m.hidden) || m.fc2.k != m.fc1.n) return PIO_E_SHAPE;
+                    hipStream_t s, const LnFold *fold_in = nullptr, const LnFold *fold_out = nullptr,
+                    int64_t out_ld = 0) {
+    if (!out_ld) out_ld = m.out;
+    if (m.fc1.k != padc(m.in) || m.fc1.n != padc(m.hidden) || m.fc2.k != m.fc1.n) return PIO_E_SHAPE;
     PIO_TRY(linear_fwd(m.fc1, m.dtype, x, rows, h.hi, h.lo, false, 0, m.fc1.n, 1, nullptr, s, fold_in));
-    return linear_fwd(m.fc2, m.dtype, h, rows, out, nullptr, true, m.out, m.out, 0, res, s, fold_out);
+    return linear_fwd(m.fc2, m.dtype, h, rows, out, nullptr, true, m.out, out_ld, 0, res, s, fold_out);
 }
 
 // ======================================================================================================
@@ -420,9 +433,9 @@ struct AttentionPlan {
         Carver c(base);
         const bool sp = a.act_split != 0;
         const int Bq = qb ? 1 : B;
-        xq16 = take_pair(c, (size_t)Bq * Tq * pad8(a.q_in), sp);
-        xk16 = take_pair(c, (size_t)B * Tk * pad8(a.k_in), sp);
-        xv16 = same ? xk16 : take_pair(c, (size_t)B * Tk * pad8(a.v_in), sp);
+        xq16 = take_pair(c, (size_t)Bq * Tq * padc(a.q_in), sp);
+        xk16 = take_pair(c, (size_t)B * Tk * padc(a.k_in), sp);
+        xv16 = same ? xk16 : take_pair(c, (size_t)B * Tk * padc(a.v_in), sp);
         core.carve(c, a, Bq, B, Tq, Tk);
         return c.off;
     }
@@ -457,9 +470,9 @@ struct SelfPlan {
     size_t carve(void *base, const pio_self_attention_t &sa, int B, int N, bool lean = false) {
         Carver c(base);
         const int64_t rows = (int64_t)B * N;
-        const int cmax = pad8(sa.attn.q_in) > pad8(sa.mlp.in) ? pad8(sa.attn.q_in) : pad8(sa.mlp.in);
+        const int cmax = padc(sa.attn.q_in) > padc(sa.mlp.in) ? padc(sa.attn.q_in) : padc(sa.mlp.in);
         x16 = take_pair(c, (size_t)rows * cmax, sa.attn.act_split || sa.mlp.act_split);
-        h16 = take_pair(c, (size_t)rows * pad8(sa.mlp.hidden), sa.mlp.act_split != 0);
+        h16 = take_pair(c, (size_t)rows * padc(sa.mlp.hidden), sa.mlp.act_split != 0);
         x1 = (float *)c.take((size_t)rows * sa.attn.out * 4);
         core.carve(c, sa.attn, B, B, N, N, !(lean && fused_capable(sa.attn, N)));
         if (sa.fold.qkv.w_hi && sa.fold.fc1.w_hi) {
@@ -572,14 +585,14 @@ static int self_attention_run(const pio_self_attention_t &sa, const pio_tensor3_
     }
     // LN1 -> attention -> + x     (transformer_primitives.py:281-290)
     const Pair xa = pair_if(p.x16, sa.attn.act_split);
-    PIO_TRY(cast_pair(x, &sa.ln1, xa, pad8(x.C), sa.attn.dtype, s));
+    PIO_TRY(cast_pair(x, &sa.ln1, xa, padc(x.C), sa.attn.dtype, s));
     const Residual rx = residual_of(x);
     PIO_TRY(attention_core(sa.attn, xa, false, xa, xa, B, N, N, kv_mask, q_mask, full_mask, attention_bias, &rx, p.x1,
                            probs_out, p.core, s));
     // LN2 -> MLP -> + x1          (transformer_primitives.py:292)
     pio_tensor3_t t1 = {p.x1, (int64_t)N * x.C, x.C, B, N, x.C};
     const Pair xm = pair_if(p.x16, sa.mlp.act_split);
-    PIO_TRY(cast_pair(t1, &sa.ln2, xm, pad8(x.C), sa.mlp.dtype, s));
+    PIO_TRY(cast_pair(t1, &sa.ln2, xm, padc(x.C), sa.mlp.dtype, s));
     const Residual r1 = residual_of(t1);
     return mlp_core(sa.mlp, xm, rows, p.h16, &r1, out, s);
 }
@@ -596,10 +609,10 @@ struct CrossPlan {
         const int64_t rows = (int64_t)B * Tq;
         const bool sp = ca.attn.act_split || ca.mlp.act_split;
         // q16 is reused for LN2(x1): size it for all B*Tq rows
-        q16 = take_pair(c, (size_t)rows * pad8(ca.attn.q_in), sp);
-        kv16 = take_pair(c, (size_t)B * Tk * pad8(ca.attn.k_in), ca.attn.act_split != 0);
-        h16 = take_pair(c, (size_t)rows * pad8(ca.mlp.hidden), ca.mlp.act_split != 0);
-        x1 = (float *)c.take((size_t)rows * ca.attn.out * 4);
+        q16 = take_pair(c, (size_t)rows * padc(ca.attn.q_in), sp);
+        kv16 = take_pair(c, (size_t)B * Tk * padc(ca.attn.k_in), ca.attn.act_split != 0);
+        h16 = take_pair(c, (size_t)rows * padc(ca.mlp.hidden), ca.mlp.act_split != 0);
+        x1 = (float *)c.take((size_t)rows * pitch4(ca.attn.out) * 4);
         core.carve(c, ca.attn, Bq, B, Tq, Tk, !(lean && fused_capable(ca.attn, Tk)));
         return c.off;
     }
@@ -611,7 +624,7 @@ struct CrossPlan {
 static int cross_attention_run(const pio_cross_attention_t &ca, const pio_tensor3_t &iq, const pio_tensor3_t &ikv,
                                const uint8_t *kv_mask, const uint8_t *q_mask, const uint8_t *full_mask,
                                const float *attention_bias, float *out, float *probs_out, CrossPlan &p,
-                               hipStream_t s, const pio_tensor3_t *ikv_tail = nullptr) {
+                               hipStream_t s, const pio_tensor3_t *ikv_tail = nullptr, int64_t out_ld = 0) {
     const int B = iq.B, Tq = iq.T, Tk = ikv.T;
     const int64_t rows = (int64_t)B * Tq;
     const int kv_c = ikv.C + (ikv_tail ? ikv_tail->C : 0);
@@ -619,21 +632,22 @@ static int cross_attention_run(const pio_cross_attention_t &ca, const pio_tensor
     if (ca.attn.out != iq.C || ca.mlp.in != iq.C || ca.mlp.out != iq.C) return PIO_E_SHAPE;
     // layer_norm_kv, layer_norm_q  (transformer_primitives.py:379-380)
     if (ikv_tail)
-        PIO_TRY(layernorm_cast_cat_launch(ikv, *ikv_tail, ca.ln_kv, p.kv16.hi, p.kv16.lo, pad8(kv_c), ca.attn.dtype, s));
+        PIO_TRY(layernorm_cast_cat_launch(ikv, *ikv_tail, ca.ln_kv, p.kv16.hi, p.kv16.lo, padc(kv_c), ca.attn.dtype, s));
     else
-        PIO_TRY(cast_pair(ikv, &ca.ln_kv, p.kv16, pad8(ikv.C), ca.attn.dtype, s));
+        PIO_TRY(cast_pair(ikv, &ca.ln_kv, p.kv16, padc(ikv.C), ca.attn.dtype, s));
     const pio_tensor3_t q1 = p.q_bcast ? first_batch(iq) : iq;
     const Pair qa = pair_if(p.q16, ca.attn.act_split);
-    PIO_TRY(cast_pair(q1, &ca.ln_q, qa, pad8(iq.C), ca.attn.dtype, s));
+    PIO_TRY(cast_pair(q1, &ca.ln_q, qa, padc(iq.C), ca.attn.dtype, s));
     const Residual rq = residual_of(iq);
     PIO_TRY(attention_core(ca.attn, qa, p.q_bcast, p.kv16, p.kv16, B, Tq, Tk, kv_mask, q_mask, full_mask,
-                           attention_bias, ca.use_query_residual ? &rq : nullptr, p.x1, probs_out, p.core, s));
+                           attention_bias, ca.use_query_residual ? &rq : nullptr, p.x1, probs_out, p.core, s, nullptr,
+                           nullptr, pitch4(iq.C)));
     // x + MLP(LN2(x))  (transformer_primitives.py:401)
-    pio_tensor3_t t1 = {p.x1, (int64_t)Tq * iq.C, iq.C, B, Tq, iq.C};
+    pio_tensor3_t t1 = {p.x1, (int64_t)Tq * pitch4(iq.C), pitch4(iq.C), B, Tq, iq.C};
     const Pair qm = pair_if(p.q16, ca.mlp.act_split);
-    PIO_TRY(cast_pair(t1, &ca.ln2, qm, pad8(iq.C), ca.mlp.dtype, s));
+    PIO_TRY(cast_pair(t1, &ca.ln2, qm, padc(iq.C), ca.mlp.dtype, s));
     const Residual r1 = residual_of(t1);
-    return mlp_core(ca.mlp, qm, rows, p.h16, &r1, out, s);
+    return mlp_core(ca.mlp, qm, rows, p.h16, &r1, out, s, nullptr, nullptr, out_ld);
 }
 
 struct DecoderPlan {
@@ -647,8 +661,8 @@ struct DecoderPlan {
         y = nullptr;
         y16 = Pair();
         if (fin) {
-            y = (float *)c.take((size_t)rows * cross.attn.q_in * 4);
-            y16 = take_pair(c, (size_t)rows * pad8(cross.attn.q_in), cross.mlp.act_split != 0);
+            y = (float *)c.take((size_t)rows * pitch4(cross.attn.q_in) * 4);
+            y16 = take_pair(c, (size_t)rows * padc(cross.attn.q_in), cross.mlp.act_split != 0);
         }
         const size_t inner = cp.carve(base ? (char *)base + c.off : nullptr, cross, B, Q, N, qb, true);
         return c.off + inner;
@@ -681,9 +695,9 @@ int pio_attention_fwd(const pio_attention_t *a, const pio_tensor3_t *iq, const p
     AttentionPlan p;
     if (p.carve(workspace, *a, B, Tq, Tk, qb, same) > workspace_bytes) return PIO_E_WORKSPACE;
     const pio_tensor3_t q1 = qb ? first_batch(*iq) : *iq;
-    PIO_TRY(cast_pair(q1, nullptr, p.xq16, pad8(a->q_in), a->dtype, s));
-    PIO_TRY(cast_pair(*ik, nullptr, p.xk16, pad8(a->k_in), a->dtype, s));
-    if (!same) PIO_TRY(cast_pair(*iv, nullptr, p.xv16, pad8(a->v_in), a->dtype, s));
+    PIO_TRY(cast_pair(q1, nullptr, p.xq16, padc(a->q_in), a->dtype, s));
+    PIO_TRY(cast_pair(*ik, nullptr, p.xk16, padc(a->k_in), a->dtype, s));
+    if (!same) PIO_TRY(cast_pair(*iv, nullptr, p.xv16, padc(a->v_in), a->dtype, s));
     return attention_core(*a, p.xq16, qb, p.xk16, p.xv16, B, Tq, Tk, kv_mask, q_mask, full_mask, attention_bias,
                           nullptr, out, probs_out, p.core, s);
 }
@@ -694,8 +708,8 @@ int pio_attention_fwd(const pio_attention_t *a, const pio_tensor3_t *iq, const p
 size_t pio_mlp_workspace_bytes(const pio_mlp_t *m, int64_t rows) {
     if (!m) return 0;
     Carver c(nullptr);
-    take_pair(c, (size_t)rows * pad8(m->in), m->act_split != 0);
-    take_pair(c, (size_t)rows * pad8(m->hidden), m->act_split != 0);
+    take_pair(c, (size_t)rows * padc(m->in), m->act_split != 0);
+    take_pair(c, (size_t)rows * padc(m->hidden), m->act_split != 0);
     return c.off;
 }
 
@@ -707,9 +721,9 @@ int pio_mlp_fwd(const pio_mlp_t *m, const pio_tensor3_t *x, float *out, void *wo
     if (pio_mlp_workspace_bytes(m, rows) > workspace_bytes) return PIO_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     Carver c(workspace);
-    const Pair x16 = take_pair(c, (size_t)rows * pad8(m->in), m->act_split != 0);
-    const Pair h16 = take_pair(c, (size_t)rows * pad8(m->hidden), m->act_split != 0);
-    PIO_TRY(cast_pair(*x, nullptr, x16, pad8(m->in), m->dtype, s));
+    const Pair x16 = take_pair(c, (size_t)rows * padc(m->in), m->act_split != 0);
+    const Pair h16 = take_pair(c, (size_t)rows * padc(m->hidden), m->act_split != 0);
+    PIO_TRY(cast_pair(*x, nullptr, x16, padc(m->in), m->dtype, s));
     return mlp_core(*m, x16, rows, h16, nullptr, out, s);
 }
 
@@ -829,13 +843,14 @@ int pio_decoder_fwd(const pio_cross_attention_t *cross, const pio_linear_t *fina
     if (p.carve(workspace, *cross, final_layer, B, Q, N, qb) > workspace_bytes) return PIO_E_WORKSPACE;
     // perceiver.py:172-177: mask[b,i,j] = query_mask[b,i]
     float *y = final_layer ? p.y : out;
+    const int64_t y_ld = final_layer ? pitch4(query->C) : query->C;  // (y is internal when a final layer follows)
     PIO_TRY(cross_attention_run(*cross, *query, *latents, nullptr, query_mask, nullptr, nullptr, y, nullptr, p.cp,
-                                s));
+                                s, nullptr, y_ld));
     if (!final_layer) return PIO_OK;
     // perceiver.py:178-179: final nn.Linear on every query row
-    if (final_layer->k != pad8(query->C)) return PIO_E_SHAPE;
-    const pio_tensor3_t ty = {y, (int64_t)Q * query->C, query->C, B, Q, query->C};
-    PIO_TRY(cast_pair(ty, nullptr, p.y16, pad8(query->C), cross->attn.dtype, s));
+    if (final_layer->k != padc(query->C)) return PIO_E_SHAPE;
+    const pio_tensor3_t ty = {y, (int64_t)Q * y_ld, y_ld, B, Q, query->C};
+    PIO_TRY(cast_pair(ty, nullptr, p.y16, padc(query->C), cross->attn.dtype, s));
     return linear_fwd(*final_layer, cross->attn.dtype, p.y16, (int64_t)B * Q, out, nullptr, true, final_out, final_out,
                       0, nullptr, s);
 }

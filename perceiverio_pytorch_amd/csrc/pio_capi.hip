@@ -128,6 +128,7 @@ const char *pio_error_string(int code) {
 }
 
 int32_t pio_pad8(int32_t c) { return pad8(c); }
+int32_t pio_padc(int32_t c) { return padc(c); }
 
 int pio_gemm_kernel_override(int which) { return gemm_kernel_override(which); }
 

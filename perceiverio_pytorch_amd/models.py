@@ -255,14 +255,14 @@ class MultiModalPerceiver(nn.Module):
                  num_classes: int = 700, audio_samples_per_frame: int = 48000 // 25,
                  audio_samples_per_patch: int = 16, num_self_attends_per_block: int = 8, num_blocks: int = 1,
                  num_latents: int = 28 * 28 * 1, num_latent_channels: int = 512, encode_once: bool = True,
-                 precision_policy: str = DEFAULT_POLICY["MultiModalPerceiver"], decode_chunks_per_call: int = 4):
+                 precision_policy: str = DEFAULT_POLICY["MultiModalPerceiver"], decode_chunks_per_call: int = 16):
         super().__init__()
         self.precision_policy = precision_policy
         # (encode_once only) how many of the n_chunks output chunks one decoder call handles: chunk k's query points
         # are the contiguous index range [k * size, (k + 1) * size), so g consecutive chunks are one range g times as
         # long -- same rows, same order, 1/g of the launches on g-times-taller (better filled) GEMMs.  Measured, full
-        # size, one sample, 128 chunks: g = 1 125 ms, 2 79 ms, 4 58 ms; from g = 8 on the 200 MB query arrays make
-        # torch's caching allocator go back to hipMalloc every few calls (400 ms) -- hence 4.
+        # size, one sample, 128 chunks (tools/mm_chunks_probe.py; ms per forward / peak GiB): g = 4 31.4 / 4.3, 8 29.1 /
+        # 5.0, 16 27.6 / 6.5, 32 26.7 / 9.6, 128 25.3 / 26.5 -- the decoder workspace grows with batch x g, hence 16.
         self.decode_chunks_per_call = max(1, int(decode_chunks_per_call))
         self.H, self.W = img_size
         self.num_classes = num_classes
@@ -349,8 +349,12 @@ class MultiModalPerceiver(nn.Module):
         step = self.decode_chunks_per_call if self.encode_once else 1
         for k in range(0, n_chunks, step):
             g = min(step, n_chunks - k)
-            points = {"image": torch.arange(img_chunk * k, img_chunk * (k + g)),
-                      "audio": torch.arange(aud_chunk * k, aud_chunk * (k + g)), "label": None}
+            # (index ranges made ON THE DEVICE: a CPU torch.arange of more than 32 768 elements runs on the intra-op
+            #  thread pool, whose spinning workers exhaust a container's CPU quota -- the process is then throttled
+            #  for the rest of the scheduler period and the GPU queue starves for ~90 ms, several times per forward)
+            dev = images.device
+            points = {"image": torch.arange(img_chunk * k, img_chunk * (k + g), device=dev),
+                      "audio": torch.arange(aud_chunk * k, aud_chunk * (k + g), device=dev), "label": None}
             if not self.encode_once:
                 out = P(inputs, subsampled_output_points=points)
             else:

@@ -160,6 +160,12 @@ def pad8(c: int) -> int:
     return (c + 7) & ~7
 
 
+def padc(c: int) -> int:
+    """Pitch of a CHANNEL axis in the 16-bit operand arrays (csrc/pio_internal.h padc): a multiple of 8, from 512
+    channels on a multiple of 64 (the staged GEMM kernels read whole 64-deep K slices)."""
+    return (c + 63) & ~63 if c >= 512 else (c + 7) & ~7
+
+
 # ------------------------------------------------------------------------------------------------
 # backend.  "hip" (default): the hot path exists only as gfx950 kernels -- CPU tensors raise.  "torch": the opt-in CPU
 # PLUMBING backend (cpu_plumbing.py) for machines without a GPU (BASELINE config 1) -- CUDA tensors raise.  Nothing ever
@@ -350,22 +356,26 @@ class PackedLinear:
     """Device image of one nn.Linear in kernel layout (hi [+ lo] + padded bias) and its descriptor."""
 
     def __init__(self, weight: torch.Tensor, bias: Optional[torch.Tensor], row_heads: int, col_heads: int,
-                 dtype: int, two_pass: bool):
+                 dtype: int, two_pass: bool, *, k_channels: bool = True, n_channels: bool = False):
+        """`k_channels`: the input axis is a channel axis (pitch padc) -- everything but Attention.final, whose input
+        is heads x padded head dim; `n_channels`: so is the OUTPUT (MLP.fc1: its 16-bit output is fc2's operand)."""
         require_device(weight, "pack_linear")
         lib = L.lib()
         out, inn = weight.shape
         if out % row_heads or inn % col_heads:
             raise ValueError("channels must be divisible by the head count")
-        self.n = row_heads * pad8(out // row_heads)
-        self.k = col_heads * pad8(inn // col_heads)
+        rows_packed = row_heads * pad8(out // row_heads)
+        self.n = padc(out) if (n_channels and row_heads == 1) else rows_packed
+        self.k = padc(inn) if (k_channels and col_heads == 1) else col_heads * pad8(inn // col_heads)
         dev = weight.device
         w = weight.detach()
         if w.dtype != torch.float32 or not w.is_contiguous():
             w = w.float().contiguous()
         tdt = torch.float16 if dtype == L.PIO_DT_F16 else torch.bfloat16
-        self.hi = torch.empty((self.n, self.k), dtype=tdt, device=dev)
-        self.lo = torch.empty((self.n, self.k), dtype=tdt, device=dev) if two_pass else None
-        self.bias = torch.empty((self.n,), dtype=torch.float32, device=dev)
+        alloc = torch.zeros if self.n > rows_packed else torch.empty     # (rows behind the packed ones stay zero)
+        self.hi = alloc((self.n, self.k), dtype=tdt, device=dev)
+        self.lo = alloc((self.n, self.k), dtype=tdt, device=dev) if two_pass else None
+        self.bias = alloc((self.n,), dtype=torch.float32, device=dev)
         b = None
         if bias is not None:
             b = bias.detach()
@@ -395,7 +405,7 @@ class PackedStack:
         require_device(w0, "pack_linear")
         dev = w0.device
         inn = w0.shape[1]
-        self.k = pad8(inn)
+        self.k = padc(inn)
         rows = [row_heads * pad8(w.shape[0] // row_heads) for w, _ in pairs]
         self.n = sum(rows)
         tdt = torch.float16 if dtype == L.PIO_DT_F16 else torch.bfloat16

@@ -134,7 +134,7 @@ class Attention(_HipModule):
         q = R.PackedLinear(self.proj_q.weight, self.proj_q.bias, H, 1, dtype, two)
         k = R.PackedLinear(self.proj_k.weight, self.proj_k.bias, H, 1, dtype, two)
         v = R.PackedLinear(self.proj_v.weight, self.proj_v.bias, H, 1, dtype, wlevel >= 1)
-        o = R.PackedLinear(self.final.weight, self.final.bias, 1, H, dtype, wlevel >= 1)
+        o = R.PackedLinear(self.final.weight, self.final.bias, 1, H, dtype, wlevel >= 1, k_channels=False)
         dk, dv = self._qk_channels_per_head, self._v_channels_per_head
         d = L.Attention(q.desc, k.desc, v.desc, o.desc, H, dk, dv, R.pad8(dk), R.pad8(dv),
                         self.proj_q.in_features, self.proj_k.in_features, self.proj_v.in_features,
@@ -221,7 +221,7 @@ class MLP(_HipModule):
     def _build_desc(self):
         dtype, wlevel, split = R.policy_dtype()
         two = wlevel >= 2
-        f1 = R.PackedLinear(self.fc1.weight, self.fc1.bias, 1, 1, dtype, two)
+        f1 = R.PackedLinear(self.fc1.weight, self.fc1.bias, 1, 1, dtype, two, n_channels=True)
         f2 = R.PackedLinear(self.fc2.weight, self.fc2.bias, 1, 1, dtype, two)
         d = L.Mlp(f1.desc, f2.desc, self.fc1.in_features, self.fc1.out_features, self.fc2.out_features, dtype,
                   int(split))
@@ -310,7 +310,7 @@ class SelfAttention(_HipModule):
             # (the split levels of the un-folded descriptors: proj_v from "x2s" on, fc1 from "x2w" on)
             qkv = R.PackedStack([folded(att.proj_q, g1, b1), folded(att.proj_k, g1, b1), folded(att.proj_v, g1, b1)],
                                 H, dtype, [False, False, wlevel >= 1])
-            fc1 = R.PackedLinear(*folded(mlp.fc1, g2, b2), 1, 1, dtype, wlevel >= 2)
+            fc1 = R.PackedLinear(*folded(mlp.fc1, g2, b2), 1, 1, dtype, wlevel >= 2, n_channels=True)
             # c[n] = sum_k of the packed weights the GEMM actually multiplies with: hi (+ lo where there is one)
             qkv_c = (qkv.hi.float() + (qkv.lo.float() if qkv.lo is not None else 0)).sum(1).contiguous()
             fc1_c = (fc1.hi.float() + (fc1.lo.float() if fc1.lo is not None else 0)).sum(1).contiguous()
