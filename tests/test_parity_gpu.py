@@ -559,6 +559,31 @@ def test_oracle_same_inputs_mid(dev):
     _assert_close(y, ref, TIGHT, what="tails")
 
 
+@pytest.mark.parametrize("policy", ["fp16x3", "fp16x2af", "fp16"])
+@pytest.mark.parametrize("Dq,resid,Q", [(1026, False, 2300), (1026, True, 2300), (522, False, 1100), (1022, True, 700)])
+def test_decoder_odd_wide_query_channels_vs_oracle(dev, Dq, resid, Q, policy):
+    """Decoder query channel counts that are neither multiples of 64 nor of 4 (the multimodal decoder has 1026): the
+    16-bit operands run on the channel pitch pio_padc (1088 / 576 / 1024) and the decoder's internal fp32 rows on a
+    float4 pitch, which takes the 2 x 2300-row GEMMs to the staged kernels -- against the float64 oracle, with and
+    without the query residual (whose rows keep the caller's pitch), query mask included."""
+    _policy(policy)
+    try:
+        cfg = dict(B=2, M=90, C=40, N=96, D=256, L=1, blocks=1, xh=1, sh=4, enc_resid=True, Q=Q, Dq=Dq, out=24, dh=1,
+                   dec_resid=resid, masks=True)
+        p_enc, p_dec, qtab, x, im, qm = gen_encdec_inputs(f"odd{Dq}", cfg, 9)
+        enc, dec = build_encdec(cfg, p_enc, p_dec, dev)
+        z, y = run_encdec(enc, dec, x, qtab, im, qm, dev)
+        c64 = lambda d: {k: a.astype(np.float64) for k, a in d.items()}  # noqa: E731
+        ref = O.encode_decode(c64(p_enc), c64(p_dec), x.astype(np.float64), qtab.astype(np.float64),
+                              **encdec_kwargs(cfg, im, qm))
+        # (single-sweep "fp16" on a dense decoder is not a shipped combination -- models.DEFAULT_POLICY gives dense
+        #  decoders split activations, "x2af" -- it runs here for the single-sweep kernels' pitch handling: 2e-3)
+        tol = {"fp16x3": TIGHT, "fp16x2af": TOL, "fp16": 2e-3}[policy]
+        _assert_close(y, ref, tol, what=f"decoder Dq={Dq} resid={resid} {policy}")
+    finally:
+        _policy("fp16x3")
+
+
 # ----------------------------------------------------------------------------------------------------
 # edge cases the reference's semantics define (SURVEY.md appendix A / C)
 # ----------------------------------------------------------------------------------------------------
