@@ -7,6 +7,17 @@
 
 using namespace pio;
 
+namespace pio {
+int padc_min() {
+    static const int v = [] {
+        const char *e = getenv("PIO_PADC_MIN");
+        return e ? atoi(e) : 512;
+    }();
+    return v;
+}
+}  // namespace pio
+
+
 // ---------------------------------------------------------------------------------------------------------
 // per-launch timing (bench only).  One global recorder: NOT thread-safe, never enabled on the product path.
 // ---------------------------------------------------------------------------------------------------------

@@ -51,7 +51,8 @@ static inline int pad8(int c) { return (c + 7) & ~7; }
 // (one 16-byte DMA piece); from 512 channels on a multiple of 64, which the staged kernels (gemm_nt_wide / _stream:
 // whole 64-deep K slices) require -- the multimodal decoder's 1026-channel queries run on 1088 (+5 % K) and its
 // GEMMs 15-25 % faster for it (tools/mm_dec_gemm_bench.py).  Head dims and key counts keep pad8.
-static inline int padc(int c) { return c >= 512 ? (c + 63) & ~63 : (c + 7) & ~7; }
+int padc_min();  // 512 (env PIO_PADC_MIN: experiments)
+static inline int padc(int c) { return c >= padc_min() ? (c + 63) & ~63 : (c + 7) & ~7; }
 
 // carve helper for caller-provided workspaces (256-byte aligned pieces)
 struct Carver {

@@ -49,13 +49,18 @@ def run(tag, M, N, K, out_f32, resid, act, n_store, ldc, override, iters=20):
           f"{us:7.1f} us  {4.0 * M * N * K / us / 1e6:7.1f} TF/s (both sweeps)", flush=True)
 
 
-M = int(sys.argv[1]) if len(sys.argv) > 1 else 25149
-for ov in ([0] if len(sys.argv) > 1 else [0, 256, 1]):
-    for K1, tag in ((1032, "pitch 1032"), (1088, "pitch 1088")):
-        run(f"q proj [{tag}]", M, 512, K1, False, False, 0, 512, 512, ov)
-        run(f"fc1 GELU [{tag}]", M, K1 if K1 == 1088 else 1032, K1, False, False, 1, K1, K1, ov)
-        run(f"fc2 + residual [{tag}]", M, 1026, K1, True, True, 0, 1026, 1026, ov)
-    run("attention out", M, 1026, 512, True, False, 0, 1026, 1026, ov)
-    run("attention out, ldc 1028", M, 1028, 512, True, False, 0, 1028, 1028, ov)
-    run("fc2 + residual, ldc 1028, K 1088", M, 1028, 1088, True, True, 0, 1028, 1028, ov)
-    run("fc2 + residual, ldc 1088, K 1088", M, 1088, 1088, True, True, 0, 1088, 1088, ov)
+def main():
+    M = int(sys.argv[1]) if len(sys.argv) > 1 else 25149
+    for ov in ([0] if len(sys.argv) > 1 else [0, 256, 1]):
+        for K1, tag in ((1032, "pitch 1032"), (1088, "pitch 1088")):
+            run(f"q proj [{tag}]", M, 512, K1, False, False, 0, 512, 512, ov)
+            run(f"fc1 GELU [{tag}]", M, K1 if K1 == 1088 else 1032, K1, False, False, 1, K1, K1, ov)
+            run(f"fc2 + residual [{tag}]", M, 1026, K1, True, True, 0, 1026, 1026, ov)
+        run("attention out", M, 1026, 512, True, False, 0, 1026, 1026, ov)
+        run("attention out, ldc 1028", M, 1028, 512, True, False, 0, 1028, 1028, ov)
+        run("fc2 + residual, ldc 1028, K 1088", M, 1028, 1088, True, True, 0, 1028, 1028, ov)
+        run("fc2 + residual, ldc 1088, K 1088", M, 1088, 1088, True, True, 0, 1088, 1088, ov)
+
+
+if __name__ == "__main__":
+    main()
