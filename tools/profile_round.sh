@@ -6,7 +6,7 @@ TAG=${1:-r1}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-BENCH="bench.py --steps 10 --warmup 3 --cpu-sample 0 --no-parity --no-extras"
+BENCH="bench.py --steps 10 --warmup 3 --cpu-sample 0 --no-parity --no-extras --launch eager"
 echo "== bench (full)"; timeout -k 10 400 python bench.py --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err || exit 1
 echo "== kernel trace"; timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python $BENCH > $OUT/trace.log 2>&1 || exit 1
 echo "== pmc fetch"; timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python $BENCH > $OUT/pmc_fetch.log 2>&1 || exit 1
