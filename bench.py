@@ -536,7 +536,9 @@ def main():
                         y_eager = forward(*inputs)
                 torch.cuda.current_stream().wait_stream(side)
                 graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
+                # (thread_local: the RCCL watchdog thread of a multi-rank run polls events while this thread captures;
+                #  tools/graph_with_rccl_probe.py)
+                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                     graph_out = forward(*inputs)
                 graph.replay()
                 torch.cuda.synchronize()
