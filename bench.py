@@ -54,7 +54,10 @@ CONFIGS = {
                      # the gate runs on EVERY B = 4 reference golden (five seeds + natural-image statistics), worst case reported
                      parity_goldens=["model_classify_b4_s31", "model_classify_b4_s32", "model_classify_b4_s33",
                                      "model_classify_b4_s34", "model_classify_b4_s35", "model_classify_b4_natural"],
-                     batch=32, policy="fp16",
+                     # "fp16sd": single-sweep fp16 with error-feedback rounding of the weights the 8 blocks share (one packed
+                     # image set per block; same kernels and time as "fp16", worst golden 6.6e-4 / 7.3e-4 against 7.7e-4 /
+                     # 8.2e-4 -- runtime.py _POLICIES, tools/sd_parity.py)
+                     batch=32, policy="fp16sd",
                      gflop=381.65, scaling="weak",
                      metric="samples/sec PerceiverIO fwd (ImageNet-224, 512x1024 latents, 8 blocks x 6 self-attends)",
                      workload="imagenet224 ClassificationPerceiver (conv+Fourier prep -> encoder 3136x322->512x1024, "
@@ -581,6 +584,7 @@ def main():
 
     NCLS = 9  # PIO_PROF_CLASSES
     eager_line = None
+    plain16 = None
     with torch.inference_mode():
         elapsed = timed_region(warmup, steps)
         if graph is not None:
@@ -651,7 +655,7 @@ def main():
             from perceiverio_pytorch_amd.models import DEFAULT_POLICY
             dflt = DEFAULT_POLICY["ClassificationPerceiver"]
             other = {}
-            for pol in ([dflt, "fp16x2s"] if not args.hot_path_only else []):
+            for pol in ([dflt, "fp16x2s", "fp16"] if not args.hot_path_only else []):
                 if pol == policy or pol in other:
                     continue
                 model.precision_policy = pol
@@ -662,6 +666,7 @@ def main():
             model.precision_policy = policy
             class_default = other.get(dflt)
             robust = other.get("fp16x2s")
+            plain16 = other.get("fp16")
 
     ms_per_step = elapsed / steps * 1e3
     samples_per_step = B if (name == "flow") else world * B
@@ -730,6 +735,8 @@ def main():
         # weights of proj_v and final as (hi, lo) pairs: 4.8e-4 / 5.3e-4 against the reference on the B = 4 golden --
         # the policy to quote if the 1e-3 bar must hold with a 2x margin (the headline policy sits at 7.3e-4 / 8.4e-4)
         out["margin_2x_policy"] = robust
+    if plain16 is not None:
+        out["plain_fp16_policy"] = plain16       # one image per shared weight (round-to-nearest): same launches
     if rank == 0 and world == 1:
         nb = args.cpu_sample if args.cpu_sample is not None else {"imagenet": 8, "language": 4, "flow": 1,
                                                                   "multimodal": 1}[name]

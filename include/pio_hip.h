@@ -338,6 +338,17 @@ int pio_encoder_fwd_split(const pio_cross_attention_t *cross, const pio_self_att
                           const pio_tensor3_t *latents, const uint8_t *input_mask, float *out, void *workspace,
                           size_t workspace_bytes, void *stream);
 
+/* The same with ONE SET OF PACKED IMAGES PER BLOCK (per_block != 0): block b runs layers[b*L .. b*L + L).  The
+ * reference shares the parameters of the L layers over the num_blocks blocks (perceiver.py:104-106); with one 16-bit
+ * image per weight its rounding error then acts num_blocks times in the same direction.  Under the "fp16sd" policy
+ * the binder packs block b from fp16(W + E_{b-1}), E_b = (W + E_{b-1}) - image_b (error feedback over the block index:
+ * every image is a rounding of W within one ulp, their accumulated error stays below half an ulp) -- same shapes,
+ * same kernels, same time.  per_block == 0: pio_encoder_fwd_split.  Workspace as pio_encoder_workspace_bytes. */
+int pio_encoder_fwd_blocks(const pio_cross_attention_t *cross, const pio_self_attention_t *layers, int32_t L,
+                           int32_t num_blocks, int32_t per_block, const pio_tensor3_t *inputs,
+                           const pio_tensor3_t *inputs_tail, const pio_tensor3_t *latents, const uint8_t *input_mask,
+                           float *out, void *workspace, size_t workspace_bytes, void *stream);
+
 /* PerceiverDecoder.forward (perceiver.py:166-180): cross-attend(query <- latents, query mask) and the
  * optional final nn.Linear (final == NULL => final_project=False).  out [B,Q,out_channels] fp32. */
 size_t pio_decoder_workspace_bytes(const pio_cross_attention_t *cross, const pio_linear_t *final_layer,

@@ -123,6 +123,8 @@ SIGNATURES = {
                                   _vp, _sz, _vp]),
     "pio_encoder_fwd_split": (C.c_int, [P(CrossAttention), P(SelfAttention), _i32, _i32, P(Tensor3), P(Tensor3),
                                         P(Tensor3), _vp, _vp, _vp, _sz, _vp]),
+    "pio_encoder_fwd_blocks": (C.c_int, [P(CrossAttention), P(SelfAttention), _i32, _i32, _i32, P(Tensor3), P(Tensor3),
+                                         P(Tensor3), _vp, _vp, _vp, _sz, _vp]),
     "pio_decoder_workspace_bytes": (_sz, [P(CrossAttention), P(Linear), _i32, _i32, _i32]),
     "pio_decoder_fwd": (C.c_int, [P(CrossAttention), P(Linear), _i32, P(Tensor3), P(Tensor3), _vp, _vp, _vp, _sz,
                                   _vp]),

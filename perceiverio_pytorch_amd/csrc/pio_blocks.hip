@@ -793,6 +793,14 @@ int pio_encoder_fwd_split(const pio_cross_attention_t *cross, const pio_self_att
                           int32_t num_blocks, const pio_tensor3_t *inputs, const pio_tensor3_t *inputs_tail,
                           const pio_tensor3_t *latents, const uint8_t *input_mask, float *out, void *workspace,
                           size_t workspace_bytes, void *stream) {
+    return pio_encoder_fwd_blocks(cross, layers, L, num_blocks, 0, inputs, inputs_tail, latents, input_mask, out,
+                                  workspace, workspace_bytes, stream);
+}
+
+int pio_encoder_fwd_blocks(const pio_cross_attention_t *cross, const pio_self_attention_t *layers, int32_t L,
+                           int32_t num_blocks, int32_t per_block, const pio_tensor3_t *inputs,
+                           const pio_tensor3_t *inputs_tail, const pio_tensor3_t *latents, const uint8_t *input_mask,
+                           float *out, void *workspace, size_t workspace_bytes, void *stream) {
     if (!cross || !inputs || !latents || !out || !workspace || (L > 0 && !layers)) return PIO_E_ARG;
     if (L < 0 || num_blocks < 0) return PIO_E_SHAPE;
     hipStream_t s = (hipStream_t)stream;
@@ -811,11 +819,12 @@ int pio_encoder_fwd_split(const pio_cross_attention_t *cross, const pio_self_att
     FoldCarry carry;  // LayerNorm fold: the row statistics of z travel from one block's fc2 to the next block's q|k|v
     for (int blk = 0; blk < num_blocks; ++blk) {  // perceiver.py:104-106: weights shared across blocks
         for (int l = 0; l < L; ++l) {
+            // (per_block: block blk has its own IMAGES of the shared parameters -- same shapes -- at layers[blk * L + l])
+            const pio_self_attention_t &lay = layers[(per_block ? (size_t)blk * L : 0) + l];
             SelfPlan sp;
-            sp.carve(workspace, layers[l], B, N, true);
+            sp.carve(workspace, lay, B, N, true);
             const bool last = blk == num_blocks - 1 && l == L - 1;
-            PIO_TRY(self_attention_run(layers[l], z, nullptr, nullptr, nullptr, nullptr, out, nullptr, sp, s, &carry,
-                                       last));
+            PIO_TRY(self_attention_run(lay, z, nullptr, nullptr, nullptr, nullptr, out, nullptr, sp, s, &carry, last));
         }
     }
     return PIO_OK;

@@ -73,9 +73,17 @@ class PerceiverEncoder(nn.Module):
         dev = x.device
         cross = self.cross_attend._desc()
         Lyr = len(self.self_attends)
-        layers = (L.SelfAttention * max(Lyr, 1))()
+        # policy "fp16sd": one set of packed images per block (error-feedback rounding of the shared weights over the
+        # block index, SelfAttention._desc_blocks) -- layers[b * Lyr + i]; otherwise the Lyr shared descriptors
+        per_block = R.policy_block_feedback() and self._num_blocks > 1 and Lyr > 0
+        nset = self._num_blocks if per_block else 1
+        layers = (L.SelfAttention * max(Lyr * nset, 1))()
         for i, sa in enumerate(self.self_attends):
-            layers[i] = sa._desc()
+            if per_block:
+                for b, d in enumerate(sa._desc_blocks(self._num_blocks)):
+                    layers[b * Lyr + i] = d
+            else:
+                layers[i] = sa._desc()
         im, im_ptr = R.mask_u8(input_mask, (B, M), dev)
         out = torch.empty((B, N, D), dtype=torch.float32, device=dev)
         tail3 = R.tensor3(inputs_tail) if inputs_tail is not None else None
@@ -87,15 +95,15 @@ class PerceiverEncoder(nn.Module):
         if guard:
             flag = R.range_flag(dev)
             flag.zero_()
-            for i in range(Lyr):
+            for i in range(Lyr * nset):
                 layers[i].fold.range_flag = flag.data_ptr()
         nsplit = R.batch_streams()
-        if nsplit <= 1 or B < 2 * nsplit or B % nsplit or inputs_tail is not None:
+        if nsplit <= 1 or B < 2 * nsplit or B % nsplit or inputs_tail is not None or per_block:
             ws = R.workspace(dev, lib.pio_encoder_workspace_bytes(cross, layers, Lyr, B, M, N))
             with R.on_device(dev):
-                L.check(lib.pio_encoder_fwd_split(cross, layers, Lyr, self._num_blocks, R.tensor3(x), tail3,
-                                                  R.tensor3(z0), im_ptr, out.data_ptr(), ws.data_ptr(),
-                                                  ws.numel(), R.stream_ptr(dev)), "pio_encoder_fwd")
+                L.check(lib.pio_encoder_fwd_blocks(cross, layers, Lyr, self._num_blocks, int(per_block), R.tensor3(x),
+                                                   tail3, R.tensor3(z0), im_ptr, out.data_ptr(), ws.data_ptr(),
+                                                   ws.numel(), R.stream_ptr(dev)), "pio_encoder_fwd")
             return self._finish(out, flag, inputs, inputs_tail, latents, input_mask)
         # Samples are independent: run `nsplit` batch slices as independent kernel chains on side streams so that
         # one chain's fill / drain / HBM-bound kernels overlap the other's MFMA-bound ones (each slice still fills

@@ -35,8 +35,16 @@ _POLICIES = {"fp16": (L.PIO_DT_F16, 0, False), "fp16x2s": (L.PIO_DT_F16, 1, Fals
              # x2af: split ACTIVATIONS against single weights (A_hi B^T + A_lo B^T: two sweeps) around a single-sweep
              # fused attention core -- for decoders whose error is dominated by the rounding of wide-range inputs
              # (Fourier / position features of dense outputs), at 2/3 of the x3f cost
-             "fp16x2af": (L.PIO_DT_F16, 0, True)}
+             "fp16x2af": (L.PIO_DT_F16, 0, True),
+             # fp16sd: "fp16" with ERROR-FEEDBACK rounding of the weights an encoder shares over its blocks: block b
+             # multiplies with fp16(W + E_{b-1}), E_b = (W + E_{b-1}) - that image (first-order sigma-delta over the
+             # block index).  Every image is a rounding of W within one ulp; the error the 8 applications of a shared
+             # weight accumulate stays below half an ulp instead of growing 8-fold.  Same kernels, same time, 8 x the
+             # packed images (604 MB for the ImageNet stack); -18..-21 % error on the ImageNet goldens.  Everything
+             # that is not a weight-shared block stack runs as under "fp16".
+             "fp16sd": (L.PIO_DT_F16, 0, False)}
 _FUSED_CORE = {"fp16x3f", "bf16x3f", "fp16x2af"}
+_BLOCK_FEEDBACK = {"fp16sd"}
 _policy = os.environ.get("PIO_PRECISION", "fp16x3")
 if _policy not in _POLICIES:
     raise ValueError(f"PIO_PRECISION={_policy!r} not in {sorted(_POLICIES)}")
@@ -154,6 +162,26 @@ def capturing(device: torch.device) -> bool:
 def policy_core_single(name: Optional[str] = None) -> bool:
     """True for the "x3f" policies: split operands in the projections, single-sweep fused attention core."""
     return (name or _policy) in _FUSED_CORE
+
+
+def policy_block_feedback(name: Optional[str] = None) -> bool:
+    """True for the policies that pack one image set per block of a weight-shared stack ("fp16sd")."""
+    return (name or _policy) in _BLOCK_FEEDBACK
+
+
+def feedback_images(w: torch.Tensor, nblk: int, dtype: int):
+    """The nblk error-feedback roundings of the fp32 weight `w` to the operand dtype, as fp32 tensors that are exactly
+    representable in it (packing them is exact): image_b = round(w + E_{b-1}), E_b = (w + E_{b-1}) - image_b, E_{-1} = 0.
+    |w - image_b| < 1 ulp for every b and |sum_{b<=k} (w - image_b)| = |E_k| <= ulp / 2 for every k."""
+    tdt = torch.float16 if dtype == L.PIO_DT_F16 else torch.bfloat16
+    w = w.detach().float()
+    out, e = [], torch.zeros_like(w)
+    for _ in range(nblk):
+        t = w + e
+        hi = t.to(tdt).float()
+        e = t - hi
+        out.append(hi)
+    return out
 
 
 def pad8(c: int) -> int:
@@ -451,6 +479,8 @@ def invalidate_packed_weights(module: torch.nn.Module) -> None:
     for m in module.modules():
         if hasattr(m, "_pio_cache"):
             m._pio_cache = None
+        if hasattr(m, "_pio_block_cache"):
+            m._pio_block_cache = None
         if hasattr(m, "_final_cache"):
             m._final_cache = None
 

@@ -69,6 +69,7 @@ class _HipModule(nn.Module):
     def __init__(self):
         super().__init__()
         self._pio_cache = None      # (key, descriptor, keep-alive list)
+        self._pio_block_cache = None    # (key, [descriptor per block], keep-alive list): policy "fp16sd"
 
     def _cached(self, key, builder):
         c = self._pio_cache
@@ -78,11 +79,11 @@ class _HipModule(nn.Module):
         return c[1]
 
     def _apply(self, fn, *a, **k):       # .to()/.cuda()/.float() invalidate packed images
-        self._pio_cache = None
+        self._pio_cache = self._pio_block_cache = None
         return super()._apply(fn, *a, **k)
 
     def _load_from_state_dict(self, *a, **k):   # load_state_dict copies through .data on some paths: repack
-        self._pio_cache = None
+        self._pio_cache = self._pio_block_cache = None
         return super()._load_from_state_dict(*a, **k)
 
 
@@ -127,21 +128,23 @@ class Attention(_HipModule):
             nn.init.constant_(self.final.bias, 0)
 
     # ---- packed descriptor -------------------------------------------------------------------
-    def _build_desc(self):
+    def _build_desc(self, ov=None):
+        """`ov` (policy "fp16sd"): {linear: fp32 weight image to pack instead of its parameter} for one block."""
         dtype, wlevel, split = R.policy_dtype()
         H = self._num_heads
         two = wlevel >= 3          # proj_q / proj_k: split only under the all-split (x3) policies
-        q = R.PackedLinear(self.proj_q.weight, self.proj_q.bias, H, 1, dtype, two)
-        k = R.PackedLinear(self.proj_k.weight, self.proj_k.bias, H, 1, dtype, two)
-        v = R.PackedLinear(self.proj_v.weight, self.proj_v.bias, H, 1, dtype, wlevel >= 1)
-        o = R.PackedLinear(self.final.weight, self.final.bias, 1, H, dtype, wlevel >= 1, k_channels=False)
+        wt = (lambda lin: ov[lin]) if ov else (lambda lin: lin.weight)
+        q = R.PackedLinear(wt(self.proj_q), self.proj_q.bias, H, 1, dtype, two)
+        k = R.PackedLinear(wt(self.proj_k), self.proj_k.bias, H, 1, dtype, two)
+        v = R.PackedLinear(wt(self.proj_v), self.proj_v.bias, H, 1, dtype, wlevel >= 1)
+        o = R.PackedLinear(wt(self.final), self.final.bias, 1, H, dtype, wlevel >= 1, k_channels=False)
         dk, dv = self._qk_channels_per_head, self._v_channels_per_head
         d = L.Attention(q.desc, k.desc, v.desc, o.desc, H, dk, dv, R.pad8(dk), R.pad8(dv),
                         self.proj_q.in_features, self.proj_k.in_features, self.proj_v.in_features,
                         self.final.out_features, dtype, (2 if R.policy_core_single() else 1) if split else 0)
         keep = [q, k, v, o]
         if self.proj_q.in_features == self.proj_k.in_features and not split:
-            qk = R.PackedStack([(self.proj_q.weight, self.proj_q.bias), (self.proj_k.weight, self.proj_k.bias)],
+            qk = R.PackedStack([(wt(self.proj_q), self.proj_q.bias), (wt(self.proj_k), self.proj_k.bias)],
                                H, dtype, two)
             d.qk = qk.desc
             keep.append(qk)
@@ -150,8 +153,8 @@ class Attention(_HipModule):
             # its second K sweep for those columns only -- the library takes such an image inside the LayerNorm fold.
             if (wlevel <= 2 and not two and self.proj_v.in_features == self.proj_q.in_features and R.pad8(dk) == 128
                     and R.pad8(dv) == 128 and (wlevel == 0 or (2 * H * 128) % 256 == 0)):
-                qkv = R.PackedStack([(self.proj_q.weight, self.proj_q.bias), (self.proj_k.weight, self.proj_k.bias),
-                                     (self.proj_v.weight, self.proj_v.bias)], H, dtype, [False, False, wlevel >= 1])
+                qkv = R.PackedStack([(wt(self.proj_q), self.proj_q.bias), (wt(self.proj_k), self.proj_k.bias),
+                                     (wt(self.proj_v), self.proj_v.bias)], H, dtype, [False, False, wlevel >= 1])
                 d.qkv = qkv.desc
                 keep.append(qkv)
         return d, keep
@@ -218,11 +221,12 @@ class MLP(_HipModule):
         nn.init.constant_(self.fc2.bias, 0)
         self.dropout = nn.Dropout(dropout_prob)
 
-    def _build_desc(self):
+    def _build_desc(self, ov=None):
         dtype, wlevel, split = R.policy_dtype()
         two = wlevel >= 2
-        f1 = R.PackedLinear(self.fc1.weight, self.fc1.bias, 1, 1, dtype, two, n_channels=True)
-        f2 = R.PackedLinear(self.fc2.weight, self.fc2.bias, 1, 1, dtype, two)
+        wt = (lambda lin: ov[lin]) if ov else (lambda lin: lin.weight)
+        f1 = R.PackedLinear(wt(self.fc1), self.fc1.bias, 1, 1, dtype, two, n_channels=True)
+        f2 = R.PackedLinear(wt(self.fc2), self.fc2.bias, 1, 1, dtype, two)
         d = L.Mlp(f1.desc, f2.desc, self.fc1.in_features, self.fc1.out_features, self.fc2.out_features, dtype,
                   int(split))
         return d, [f1, f2]
@@ -288,7 +292,34 @@ class SelfAttention(_HipModule):
         self._build_ln_fold(d, a, keep)
         return d, keep + [self.attention._pio_cache, self.mlp._pio_cache]
 
-    def _build_ln_fold(self, d, a, keep):
+    def _desc_blocks(self, nblk: int):
+        """Policy "fp16sd": one descriptor per block of a weight-shared stack, block b packed from the b-th
+        error-feedback rounding of every weight (runtime.feedback_images) -- of W for the plain images, of W * gamma
+        for the images of the LayerNorm fold (the feedback runs over what the GEMM actually multiplies with)."""
+        key = R.param_key(*self._params()) + (nblk,)
+        c = self._pio_block_cache
+        if c is None or c[0] != key:
+            dtype, _wlevel, _split = R.policy_dtype()
+            att, mlp = self.attention, self.mlp
+            lins = (att.proj_q, att.proj_k, att.proj_v, att.final, mlp.fc1, mlp.fc2)
+            descs, keep = [], []
+            with torch.no_grad():
+                g1, g2 = self.layer_norm1.weight.float(), self.layer_norm2.weight.float()
+                plain = {lin: R.feedback_images(lin.weight, nblk, dtype) for lin in lins}
+                fold = {lin: R.feedback_images(lin.weight.float() * g[None, :], nblk, dtype)
+                        for lin, g in ((att.proj_q, g1), (att.proj_k, g1), (att.proj_v, g1), (mlp.fc1, g2))}
+                for b in range(nblk):
+                    a, ka = att._build_desc({lin: plain[lin][b] for lin in lins[:4]})
+                    m, km = mlp._build_desc({lin: plain[lin][b] for lin in lins[4:]})
+                    d = L.SelfAttention(R.layernorm_desc(self.layer_norm1, keep), R.layernorm_desc(self.layer_norm2, keep),
+                                        a, m)
+                    self._build_ln_fold(d, a, keep, {lin: imgs[b] for lin, imgs in fold.items()})
+                    descs.append(d)
+                    keep.extend([ka, km])
+            self._pio_block_cache = c = (key, descs, keep)
+        return c[1]
+
+    def _build_ln_fold(self, d, a, keep, fold_ov=None):
         """LayerNorm folded into the consuming GEMMs (pio_ln_fold_t): LN(x) W^T + b = rstd (x W'^T - mean c) + b' with
         W' = W * gamma, c = rowsum(W' as packed), b' = W beta + b (reference :281-292 computes LN then Linear).
         Offered for 1024-channel blocks under the single-sweep policies; the library decides per call."""
@@ -304,7 +335,9 @@ class SelfAttention(_HipModule):
             def folded(lin, g, b):
                 w = lin.weight.float()
                 bias = lin.bias.float() if lin.bias is not None else torch.zeros(w.shape[0], device=w.device)
-                return (w * g[None, :]).contiguous(), (w @ b + bias).contiguous()
+                # (fold_ov: this block's image of W * gamma; the bias is that of the parameters)
+                wg = fold_ov[lin] if fold_ov else w * g[None, :]
+                return wg.contiguous(), (w @ b + bias).contiguous()
 
             H = att._num_heads
             # (the split levels of the un-folded descriptors: proj_v from "x2s" on, fc1 from "x2w" on)

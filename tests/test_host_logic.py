@@ -261,3 +261,31 @@ def test_cpu_plumbing_is_not_reachable_from_the_default_backend():
         if fn.endswith(".py"):
             src = open(os.path.join(root, fn)).read()
             assert not re.search(r"^\s*(from|import)\s+(oracle|perceiver_oracle|cases)\b", src, re.M), fn
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+def test_feedback_images_are_roundings_whose_errors_cancel(dt):
+    """runtime.feedback_images (policy "fp16sd"): image_b = round(w + E_{b-1}).  Every image is exactly representable in
+    the operand dtype, lies within one ulp of w (the first IS round-to-nearest), and the error the first k images
+    accumulate stays within half an ulp for every k -- against k/2 ulp for k copies of the round-to-nearest image."""
+    import torch
+    from perceiverio_pytorch_amd import runtime as R, _lib as L
+    tdt = torch.float16 if dt == "f16" else torch.bfloat16
+    torch.manual_seed(3)
+    w = torch.randn(257, 130) * 0.05
+    w[0, :4] = torch.tensor([0.0, 1.0, -2.5e-3, 6.0e4 if dt == "f16" else 3.0e38])
+    imgs = R.feedback_images(w, 8, L.PIO_DT_F16 if dt == "f16" else L.PIO_DT_BF16)
+    assert len(imgs) == 8 and torch.equal(imgs[0], w.to(tdt).float())
+    # ulp of w in the operand dtype (normal range): 2^(floor(log2 |w|) - mantissa bits)
+    mant = 10 if dt == "f16" else 7
+    ulp = torch.where(w == 0, torch.zeros_like(w), torch.exp2(torch.floor(torch.log2(w.abs().clamp_min(1e-30))) - mant))
+    if dt == "f16":
+        ulp = ulp.clamp_min(2.0 ** -24)                      # (subnormal spacing of fp16)
+    cum = torch.zeros_like(w, dtype=torch.float64)
+    for img in imgs:
+        assert torch.equal(img.to(tdt).float(), img), "an image must be exactly representable"
+        assert bool(((w - img).abs() <= ulp * 1.0000001).all()), "an image must be a rounding of w within one ulp"
+        cum += (w.double() - img.double())
+        assert bool((cum.abs() <= 0.5000001 * ulp.double() * 2).all())      # (ulp doubles across a binade edge)
+    plain = 8 * (w.double() - imgs[0].double()).abs()
+    assert cum.abs().sum() < 0.3 * plain.sum(), "the accumulated error must be far below that of 8 equal roundings"

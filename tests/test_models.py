@@ -62,7 +62,7 @@ B4_CASES = sorted(n for n in MODEL_CASES if n.startswith("model_classify_b4_"))
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("policy", ["fp16", "fp16x2s", "fp16x2w", "fp16x3"])
+@pytest.mark.parametrize("policy", ["fp16", "fp16sd", "fp16x2s", "fp16x2w", "fp16x3"])
 @pytest.mark.parametrize("name", B4_CASES)
 def test_benchmarked_path_matches_reference(name, policy):
     """The code path bench.py times (B*512 >= 6144 latent rows: the LayerNorm fold and the 16-bit-pair residual stream
@@ -90,6 +90,17 @@ def test_benchmarked_path_matches_reference(name, policy):
         with torch.inference_mode():
             y = model(x)
         _close(y, g["out"], f"{name} [{policy}, fold forced at B=4]", tol)
+        if policy == "fp16sd":
+            # error-feedback rounding of the shared weights over the 8 blocks: the same launches as "fp16", less error on
+            # every golden (12-22 % in relL2)
+            model.precision_policy = "fp16"
+            with torch.inference_mode():
+                y16 = model(x12)
+            e_sd = O.rel_errors(y12[:4].cpu().numpy(), g["out"])[0]
+            e_16 = O.rel_errors(y16[:4].cpu().numpy(), g["out"])[0]
+            print(f"{name}: relL2 fp16sd {e_sd:.3e} / fp16 {e_16:.3e}")
+            assert e_sd < e_16, f"{name}: fp16sd {e_sd:.3e} is not below fp16 {e_16:.3e}"
+            model.precision_policy = policy
         if policy == "fp16":
             # the fold must actually have run at B = 12 (it is what bench.py times) and, automatic, must NOT at B = 4
             # (2048 rows: the un-folded block's smaller tiles are faster there -- pio_blocks.hip ln_fold_min_rows)

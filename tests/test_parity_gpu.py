@@ -1127,6 +1127,50 @@ def test_fold_range_guard_falls_back_on_overflow(dev, policy):
     assert int(R.last_range_flag(dev).item()) == 0
 
 
+@pytest.mark.parametrize("D,fold", [(1024, True), (72, False)])
+def test_per_block_images_path_equals_shared_path_when_images_are_equal(dev, D, fold, monkeypatch):
+    """Policy "fp16sd" hands pio_encoder_fwd_blocks one descriptor set per block.  With the error feedback switched off
+    (every block gets the round-to-nearest image) the result must equal policy "fp16" bit for bit -- same kernels, same
+    order, only the weight pointers differ -- with and without the LayerNorm fold; with the feedback on it must differ
+    (the images do) and stay as close to the fp16x3 result."""
+    from perceiverio_pytorch_amd import runtime as R
+    from perceiverio_pytorch_amd.perceiver import PerceiverEncoder
+    import perceiverio_pytorch_amd as P
+    lib = P.lib()
+    C_, N, Lyr, nblk = 40, 512, 2, 3
+    p_enc = O.gen_encoder(C_, N, D, Lyr, seed=21)
+    enc = PerceiverEncoder(C_, Lyr, nblk, N, D, num_self_attend_heads=8)
+    enc.load_state_dict(_sd(p_enc, "cpu"))
+    enc = enc.to(dev).eval()
+    x = _t(np.random.default_rng(4).standard_normal((4, 60, C_)).astype(np.float32), dev)
+    prev = lib.pio_ln_fold_enable(2 if fold else 0)
+    try:
+        _policy("fp16")
+        y16 = enc(x, enc.latents(x)).clone()
+        _policy("fp16sd")
+        y_sd = enc(x, enc.latents(x)).clone()
+        tdt = torch.float16
+
+        def no_feedback(w, n, dtype):
+            hi = w.detach().float().to(tdt).float()
+            return [hi for _ in range(n)]
+        monkeypatch.setattr(R, "feedback_images", no_feedback)
+        R.invalidate_packed_weights(enc)
+        y_eq = enc(x, enc.latents(x)).clone()
+        monkeypatch.undo()
+        R.invalidate_packed_weights(enc)
+        _policy("fp16x3")
+        y3 = enc(x, enc.latents(x)).clone()
+    finally:
+        lib.pio_ln_fold_enable(prev)
+        _policy("fp16x3")
+    assert torch.equal(y_eq, y16), "per-block path with equal images must reproduce the shared-image path"
+    assert not torch.equal(y_sd, y16), "error-feedback images must differ from the round-to-nearest ones"
+    e16, esd = _errs(y16, y3.cpu().numpy()), _errs(y_sd, y3.cpu().numpy())
+    print(f"D={D} fold={fold}: fp16 relL2={e16[0]:.2e} max={e16[1]:.2e} | fp16sd relL2={esd[0]:.2e} max={esd[1]:.2e}")
+    assert esd[0] <= TOL and esd[1] <= TOL
+
+
 def _fold_lib():
     import perceiverio_pytorch_amd as P
     return P.lib()
