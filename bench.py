@@ -551,6 +551,13 @@ def main():
                 raise
             print(f"[bench] HIP graph capture failed ({type(e).__name__}: {e}); timing eager launches", file=sys.stderr)
             graph, launch = None, "eager"
+    if world > 1 and (args.launch or "graph") == "graph" and name == "imagenet" and not rehearse:
+        # every rank runs the same sequence of timed regions (they contain barriers): one rank without a graph puts all
+        # ranks on eager launches
+        ok = torch.tensor([1 if graph is not None else 0], device=dev, dtype=torch.int32)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            graph, launch = None, "eager"
 
     def step(eager=False):
         if graph is not None and not eager:
