@@ -444,7 +444,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip stage timing and the class-default policy leg")
     ap.add_argument("--hot-path-only", action="store_true", help="imagenet: time encoder+decoder on a resident [B,3136,322] array")
     ap.add_argument("--launch", choices=["graph", "eager"], default=None,
-                    help="imagenet: replay the step's launches from ONE HIP graph (default) or launch them one by one")
+                    help="replay the step's launches from ONE HIP graph (default) or launch them one by one")
     args = ap.parse_args()
 
     # PIO_BENCH_REHEARSE=1 (1-GPU box): go through the same spawn + multi-rank code with every rank on cuda:0 and the
@@ -527,7 +527,8 @@ def main():
     # per-launch dispatch gaps and no host round trip for the range guard between two steps -- its device word is read
     # once, after the timed region.  Same kernels, same order, bit-identical logits (checked below against an eager
     # forward).  --launch eager times the plain module call.
-    launch = args.launch or ("graph" if name == "imagenet" and not rehearse else "eager")
+    # (flow on several ranks: its forward contains the all-gather of the query shards -- launched eagerly)
+    launch = args.launch or ("graph" if not rehearse and not (name == "flow" and world > 1) else "eager")
     graph = graph_out = None
     if launch == "graph":
         try:
@@ -545,13 +546,15 @@ def main():
                     graph_out = forward(*inputs)
                 graph.replay()
                 torch.cuda.synchronize()
-                assert torch.equal(graph_out, y_eager), "graph replay and eager forward disagree"
+                pairs = ([(graph_out[k], y_eager[k]) for k in graph_out] if isinstance(graph_out, dict)
+                         else [(graph_out, y_eager)])
+                assert all(torch.equal(a, b) for a, b in pairs), "graph replay and eager forward disagree"
         except Exception as e:  # noqa: BLE001
             if args.launch == "graph":
                 raise
             print(f"[bench] HIP graph capture failed ({type(e).__name__}: {e}); timing eager launches", file=sys.stderr)
             graph, launch = None, "eager"
-    if world > 1 and (args.launch or "graph") == "graph" and name == "imagenet" and not rehearse:
+    if world > 1 and (args.launch or "graph") == "graph" and not rehearse and name != "flow":
         # every rank runs the same sequence of timed regions (they contain barriers): one rank without a graph puts all
         # ranks on eager launches
         ok = torch.tensor([1 if graph is not None else 0], device=dev, dtype=torch.int32)
@@ -596,7 +599,8 @@ def main():
         elapsed = timed_region(warmup, steps)
         if graph is not None:
             # the fp16 range guard of the replayed steps: the word the fold's producer GEMMs report into
-            assert int(P.runtime.last_range_flag(dev).item()) == 0, "range guard fired inside the replayed steps"
+            flag_t = P.runtime.last_range_flag(dev)
+            assert flag_t is None or int(flag_t.item()) == 0, "range guard fired inside the replayed steps"
             n_e = max(3, steps // 2)
             el_e = timed_region(2, n_e, eager=True)        # the same steps launched one by one, for the record
             eager_line = {"value": (B if name == "flow" else world * B) * n_e / el_e, "unit": "samples/s",
