@@ -744,7 +744,7 @@ def main():
         out["class_default_policy"] = class_default
     if robust is not None:
         # weights of proj_v and final as (hi, lo) pairs: 4.8e-4 / 5.3e-4 against the reference on the B = 4 golden --
-        # the policy to quote if the 1e-3 bar must hold with a 2x margin (the headline policy sits at 7.3e-4 / 8.4e-4)
+        # the policy to quote if the 1e-3 bar must hold with a 2x margin (the headline policy "fp16sd" sits at 6.6e-4 / 7.3e-4, plain "fp16" at 7.7e-4 / 8.2e-4)
         out["margin_2x_policy"] = robust
     if plain16 is not None:
         out["plain_fp16_policy"] = plain16       # one image per shared weight (round-to-nearest): same launches
