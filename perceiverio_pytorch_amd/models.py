@@ -38,16 +38,31 @@ from .position_encoding import PosEncodingType
 # the weights (flow 1.6e-4 / 2.7e-4 at 7.4 ms, multimodal chunk 3.9e-4 / 4.8e-4 at 49 ms instead of 55; with split weights
 # and single activations -- "x2w" -- the max figure is 1.3-1.5e-3), and the flow encoder single-sweep fp16 (its error
 # does not show behind the decoder's: 1.07e-4 with "fp16/fp16x3f" against 1.5e-4 with "fp16x2w/fp16x3f").
-DEFAULT_POLICY = {"ClassificationPerceiver": "fp16x2w", "LanguagePerceiver": "fp16x2w",
+# Late round 3: the classifier's default is "fp16x3f/fp16sd/fp16x3f" -- the 48-layer stack single-sweep with
+# error-feedback rounding of its shared weights ("fp16sd"), the two cross-attends (weights applied once: encoder input
+# and decoder, 1.2 of 16.5 ms) with split operands around the fused single-sweep core.  Six B = 4 goldens, worst case:
+# 3.2e-4 / 3.9e-4 at 17.5 ms -- "fp16x2w" (the previous default) 3.1e-4 / 3.4e-4 at 20.8 ms, "fp16sd" alone 6.6e-4 /
+# 7.3e-4 at 16.5 ms, "fp16sd/fp16x3f" 4.2e-4 / 5.0e-4 at 17.1 ms (tools/sd_parity.py, bench.py --policy).
+DEFAULT_POLICY = {"ClassificationPerceiver": "fp16x3f/fp16sd/fp16x3f", "LanguagePerceiver": "fp16x2w",
                   "FlowPerceiver": "fp16/fp16x2af", "MultiModalPerceiver": "fp16x2w/fp16x2af"}
 
 
-def split_policy(policy):
-    """"A/B" -> (A, B); a plain name (or None) applies to both halves."""
+def split_policy3(policy):
+    """"X/A/B" -> (X, A, B): X for the encoder's cross-attend alone, A for the latent self-attend stack, B for the decoder;
+    "A/B" -> (None, A, B) (the cross-attend runs under A); a plain name (or None) applies everywhere."""
     if policy is not None and "/" in policy:
-        enc, dec = policy.split("/", 1)
-        return enc, dec
-    return policy, policy
+        parts = policy.split("/")
+        if len(parts) == 3:
+            return parts[0], parts[1], parts[2]
+        if len(parts) == 2:
+            return None, parts[0], parts[1]
+        raise ValueError(f"precision policy {policy!r}: expected 'name', 'encoder/decoder' or 'cross/stack/decoder'")
+    return None, policy, policy
+
+
+def split_policy(policy):
+    """(encoder policy, decoder policy) of a task model's policy string (split_policy3 without the cross-attend's)."""
+    return split_policy3(policy)[1:]
 
 
 class _policy_scope:
@@ -56,21 +71,28 @@ class _policy_scope:
 
     def __init__(self, model):
         self._model = model
-        enc, dec = split_policy(model.precision_policy)
+        cross, enc, dec = split_policy3(model.precision_policy)
         self._ctx = precision(enc)
         self._dec = dec if dec != enc else None
+        self._cross = cross if cross != enc else None
 
     def __enter__(self):
         # a decoder policy the USER set on the core (model.perceiver.decoder_policy = ...) wins over the decoder half of
-        # the model's "encoder/decoder" policy string; it is restored untouched afterwards either way
-        self._saved = self._model.perceiver.decoder_policy
+        # the model's "encoder/decoder" policy string; it is restored untouched afterwards either way.  Likewise the
+        # cross-attend's own policy (PerceiverEncoder.cross_attend_policy).
+        core = self._model.perceiver
+        self._saved = core.decoder_policy
         if self._saved is None:
-            self._model.perceiver.decoder_policy = self._dec
+            core.decoder_policy = self._dec
+        self._saved_cross = core._encoder.cross_attend_policy
+        if self._saved_cross is None:
+            core._encoder.cross_attend_policy = self._cross
         self._ctx.__enter__()
         return self
 
     def __exit__(self, *exc):
         self._model.perceiver.decoder_policy = self._saved
+        self._model.perceiver._encoder.cross_attend_policy = self._saved_cross
         return self._ctx.__exit__(*exc)
 
 

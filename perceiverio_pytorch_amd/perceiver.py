@@ -49,6 +49,12 @@ class PerceiverEncoder(nn.Module):
                                                    v_channels=v_channels,
                                                    widening_factor=self_attend_widening_factor))
 
+    # Optional precision policy of the cross-attend alone (None = the ambient policy).  Its weights are applied ONCE to
+    # the raw input features; the stack's 48 applications of shared weights are what single-sweep speed matters for.
+    # On the ImageNet goldens "fp16x3f" here and in the decoder with the stack on "fp16sd" gives 3.2e-4 / 3.9e-4 (worst
+    # of six) against 6.6e-4 / 7.3e-4 with "fp16sd" everywhere, for 1.1 ms of 16.4 (tools/sd_parity.py).
+    cross_attend_policy = None
+
     def latents(self, inputs):
         return self.latent_pos_enc(batch_size=inputs.shape[0])
 
@@ -71,7 +77,10 @@ class PerceiverEncoder(nn.Module):
         B, M, _ = x.shape
         N, D = z0.shape[1], z0.shape[2]
         dev = x.device
-        cross = self.cross_attend._desc()
+        # (cross_attend_policy: the cross-attend's own precision policy -- its weights are applied once, unlike the
+        #  stack's; None = the ambient policy.  The descriptor carries its dtype / split flags into the library.)
+        with R.precision(self.cross_attend_policy):
+            cross = self.cross_attend._desc()
         Lyr = len(self.self_attends)
         # policy "fp16sd": one set of packed images per block (error-feedback rounding of the shared weights over the
         # block index, SelfAttention._desc_blocks) -- layers[b * Lyr + i]; otherwise the Lyr shared descriptors

@@ -26,10 +26,12 @@ def spec_of(g):
 
 def test_default_policies_are_the_validated_ones():
     from perceiverio_pytorch_amd import models as M
-    assert M.ClassificationPerceiver().precision_policy == "fp16x2w"
-    assert M.DEFAULT_POLICY == {"ClassificationPerceiver": "fp16x2w", "LanguagePerceiver": "fp16x2w",
+    assert M.ClassificationPerceiver().precision_policy == "fp16x3f/fp16sd/fp16x3f"
+    assert M.DEFAULT_POLICY == {"ClassificationPerceiver": "fp16x3f/fp16sd/fp16x3f", "LanguagePerceiver": "fp16x2w",
                                 "FlowPerceiver": "fp16/fp16x2af", "MultiModalPerceiver": "fp16x2w/fp16x2af"}
     assert M.split_policy("fp16x2w/fp16x3") == ("fp16x2w", "fp16x3") and M.split_policy("fp16") == ("fp16", "fp16")
+    assert M.split_policy3("fp16x3f/fp16sd/fp16x2af") == ("fp16x3f", "fp16sd", "fp16x2af")
+    assert M.split_policy3("fp16/fp16x3") == (None, "fp16", "fp16x3") and M.split_policy("a/b/c") == ("b", "c")
 
 
 @pytest.mark.parametrize("name", sorted(MODEL_CASES))
@@ -62,7 +64,8 @@ B4_CASES = sorted(n for n in MODEL_CASES if n.startswith("model_classify_b4_"))
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("policy", ["fp16", "fp16sd", "fp16x2s", "fp16x2w", "fp16x3"])
+@pytest.mark.parametrize("policy", ["fp16", "fp16sd", "fp16sd/fp16x3f", "fp16x3f/fp16sd/fp16x3f", "fp16x2s", "fp16x2w",
+                                    "fp16x3"])
 @pytest.mark.parametrize("name", B4_CASES)
 def test_benchmarked_path_matches_reference(name, policy):
     """The code path bench.py times (B*512 >= 6144 latent rows: the LayerNorm fold and the 16-bit-pair residual stream

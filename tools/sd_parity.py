@@ -22,7 +22,7 @@ for name in Bn.CONFIGS["imagenet"]["parity_goldens"]:
     x = torch.from_numpy(model_inputs(name)[0]).to(dev).repeat(3, 1, 1, 1)
     line = f"{name:28s}"
     for pol in pols:
-        model.precision_policy = pol
+        model.precision_policy = pol                 # "name", "encoder/decoder" or "cross/stack/decoder"
         with torch.inference_mode():
             y = model(x).cpu().numpy().reshape(3, *g["out"].shape)
         e = [max(v) for v in zip(*(Bn.rel_errors(yc, g["out"]) for yc in y))]
