@@ -68,7 +68,8 @@ CONFIGS = {
                      hot=dict(M=3136, C=322, Q=1000)),
     # (batch 100: 100 x 256 latent rows = 100 tile rows of the 256-row GEMM tilings -- 500 / 1000 tiles, whole rounds of the
     #  256 CUs; B = 32 gives 160-tile launches: 2 574 samples/s against 3 409, profiles/r3_configs.json)
-    "language": dict(golden="model_language", parity_golden="model_language", batch=100, policy="fp16x2w",
+    "language": dict(golden="model_language", parity_golden="model_language", batch=100,
+                     policy="fp16x3f/fp16x2s/fp16x3f",       # (the class default)
                      gflop=120.1, scaling="weak",
                      metric="samples/sec PerceiverIO fwd (masked-LM, 2048 byte tokens, 256x1280 latents, 26 self-attends)",
                      workload="LanguagePerceiver: 2048 byte tokens (ragged valid lengths 512..2048, input + query "

@@ -43,7 +43,10 @@ from .position_encoding import PosEncodingType
 # and decoder, 1.2 of 16.5 ms) with split operands around the fused single-sweep core.  Six B = 4 goldens, worst case:
 # 3.2e-4 / 3.9e-4 at 17.5 ms -- "fp16x2w" (the previous default) 3.1e-4 / 3.4e-4 at 20.8 ms, "fp16sd" alone 6.6e-4 /
 # 7.3e-4 at 16.5 ms, "fp16sd/fp16x3f" 4.2e-4 / 5.0e-4 at 17.1 ms (tools/sd_parity.py, bench.py --policy).
-DEFAULT_POLICY = {"ClassificationPerceiver": "fp16x3f/fp16sd/fp16x3f", "LanguagePerceiver": "fp16x2w",
+# The language model (26 distinct layers: nothing to feed back over) keeps split weights for proj_v / final in the stack
+# ("fp16x2s") and takes the same split-operand cross-attends: 3.7e-4 / 3.9e-4 at 27.6 ms for B = 100 against "fp16x2w"
+# 3.8e-4 / 4.8e-4 at 28.4 ms; "fp16/fp16x3f" (single-sweep stack) passes the bar at 6.4e-4 / 8.7e-4 and 22.8 ms.
+DEFAULT_POLICY = {"ClassificationPerceiver": "fp16x3f/fp16sd/fp16x3f", "LanguagePerceiver": "fp16x3f/fp16x2s/fp16x3f",
                   "FlowPerceiver": "fp16/fp16x2af", "MultiModalPerceiver": "fp16x2w/fp16x2af"}
 
 

@@ -27,7 +27,8 @@ def spec_of(g):
 def test_default_policies_are_the_validated_ones():
     from perceiverio_pytorch_amd import models as M
     assert M.ClassificationPerceiver().precision_policy == "fp16x3f/fp16sd/fp16x3f"
-    assert M.DEFAULT_POLICY == {"ClassificationPerceiver": "fp16x3f/fp16sd/fp16x3f", "LanguagePerceiver": "fp16x2w",
+    assert M.DEFAULT_POLICY == {"ClassificationPerceiver": "fp16x3f/fp16sd/fp16x3f",
+                                "LanguagePerceiver": "fp16x3f/fp16x2s/fp16x3f",
                                 "FlowPerceiver": "fp16/fp16x2af", "MultiModalPerceiver": "fp16x2w/fp16x2af"}
     assert M.split_policy("fp16x2w/fp16x3") == ("fp16x2w", "fp16x3") and M.split_policy("fp16") == ("fp16", "fp16")
     assert M.split_policy3("fp16x3f/fp16sd/fp16x2af") == ("fp16x3f", "fp16sd", "fp16x2af")

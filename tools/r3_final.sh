@@ -7,6 +7,9 @@ mkdir -p gpurun_out/r3_final
 for c in language flow multimodal; do
   echo "== bench $c"; timeout -k 10 400 python bench.py --config $c > gpurun_out/r3_final/$c.json 2> gpurun_out/r3_final/$c.err || exit 1
 done
-echo "== bench language fp16x2s"; timeout -k 10 400 python bench.py --config language --policy fp16x2s --cpu-sample 0 > gpurun_out/r3_final/language_fp16x2s.json 2> gpurun_out/r3_final/language_fp16x2s.err || exit 1
+for pol in fp16x2s fp16/fp16x3f fp16x3f/fp16x2s/fp16x3f; do
+  tag=$(echo $pol | tr / _)
+  echo "== bench language $pol"; timeout -k 10 400 python bench.py --config language --policy $pol --cpu-sample 0 > gpurun_out/r3_final/language_$tag.json 2> gpurun_out/r3_final/language_$tag.err || exit 1
+done
 echo "== latency"; PIO_PROBE_BATCHES=1,2,4,8,12,16,32 timeout -k 10 300 python tools/latency_probe.py > gpurun_out/r3_final/latency.txt 2>&1 || exit 1
 cat gpurun_out/r3_final/latency.txt | grep "^B="
