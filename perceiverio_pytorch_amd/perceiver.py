@@ -86,13 +86,9 @@ class PerceiverEncoder(nn.Module):
         # block index, SelfAttention._desc_blocks) -- layers[b * Lyr + i]; otherwise the Lyr shared descriptors
         per_block = R.policy_block_feedback() and self._num_blocks > 1 and Lyr > 0
         nset = self._num_blocks if per_block else 1
-        layers = (L.SelfAttention * max(Lyr * nset, 1))()
-        for i, sa in enumerate(self.self_attends):
-            if per_block:
-                for b, d in enumerate(sa._desc_blocks(self._num_blocks)):
-                    layers[b * Lyr + i] = d
-            else:
-                layers[i] = sa._desc()
+        descs = []
+        for sa in self.self_attends:
+            descs.append(sa._desc_blocks(self._num_blocks) if per_block else [sa._desc()])
         im, im_ptr = R.mask_u8(input_mask, (B, M), dev)
         out = torch.empty((B, N, D), dtype=torch.float32, device=dev)
         tail3 = R.tensor3(inputs_tail) if inputs_tail is not None else None
@@ -104,8 +100,20 @@ class PerceiverEncoder(nn.Module):
         if guard:
             flag = R.range_flag(dev)
             flag.zero_()
-            for i in range(Lyr * nset):
-                layers[i].fold.range_flag = flag.data_ptr()
+        # the descriptor array handed to the library: rebuilt only when a descriptor or the guard word changes (the
+        # cached descriptor objects are replaced whenever their parameters / the policy change)
+        lkey = (tuple(id(d) for ds in descs for d in ds), flag.data_ptr() if guard else 0)
+        lc = self.__dict__.get("_layers_cache")
+        if lc is None or lc[0] != lkey:
+            layers = (L.SelfAttention * max(Lyr * nset, 1))()
+            for i, ds in enumerate(descs):
+                for b, d in enumerate(ds):
+                    layers[b * Lyr + i] = d
+            if guard:
+                for i in range(Lyr * nset):
+                    layers[i].fold.range_flag = flag.data_ptr()
+            self.__dict__["_layers_cache"] = lc = (lkey, layers, descs)     # (descs: keeps the ids alive)
+        layers = lc[1]
         nsplit = R.batch_streams()
         if nsplit <= 1 or B < 2 * nsplit or B % nsplit or inputs_tail is not None or per_block:
             ws = R.workspace(dev, lib.pio_encoder_workspace_bytes(cross, layers, Lyr, B, M, N))
