@@ -102,6 +102,10 @@ MODEL_CASES = {
     "model_classify_1x1": dict(cls="ClassificationPerceiver", kw=dict(prep="LEARNED_POS_1X1CONV"), batch=1),
     "model_classify_pixel": dict(cls="ClassificationPerceiver", kw=dict(prep="FOURIER_POS_PIXEL"), batch=1),
     "model_language": dict(cls="LanguagePerceiver", kw=dict(), batch=2),
+    # two more parameter / token seeds with other ragged lengths (late round 3: the class default moved to a three-part
+    # policy with a thinner stack policy; one golden was not enough to call its margin)
+    "model_language_s32": dict(cls="LanguagePerceiver", kw=dict(), batch=2, pseed=32, lengths=(2048, 333)),
+    "model_language_s33": dict(cls="LanguagePerceiver", kw=dict(), batch=2, pseed=33, lengths=(1, 1290)),
     "model_flow_small": dict(cls="FlowPerceiver", kw=dict(img_size=(48, 64), num_latents=128, num_latent_channels=128,
                                                           num_self_attends_per_block=2), batch=1),
     # full-size optical-flow configuration: M = Q = 368*496 = 182 528 tokens, 2048 x 512 latents, 24 self-attends
@@ -180,7 +184,7 @@ def model_inputs(name, seed=None):
         rng = np.random.default_rng(seed)
         tok = rng.integers(6, 262, size=(B, 2048)).astype(np.int64)
         mask = np.zeros((B, 2048), dtype=bool)
-        for b, n in zip(range(B), (60, 700)):
+        for b, n in zip(range(B), c.get("lengths", (60, 700))):
             mask[b, :n] = True
         tok[~mask] = 0
         return [tok, mask]
