@@ -207,9 +207,27 @@ def parity_check(name, model, params, dev, policy):
                            "batch), "
                            "5 parameter/input seeds + natural-image statistics; worst case gates")
         elif name == "language":
-            y = model(ins[0], ins[1]).cpu().numpy()
-            rl2, rmax = rel_errors(y[:, :96], g["out"], g["out_absmax"])
-            out["case"] = "LanguagePerceiver B=2 (60 / 700 valid tokens), logits rows 0..95"
+            # three goldens (parameter / token seeds 31 / 32 / 33, different ragged lengths): worst case gates
+            from cases import gen_state_dict, model_seed
+            per = {}
+            keep = {k: v.clone() for k, v in model.state_dict().items()}
+            for gn in ("model_language", "model_language_s32", "model_language_s33"):
+                gg = np.load(os.path.join(ROOT, "tests", "golden", gn + ".npz"))
+                if model_seed(gn) != SEED:
+                    sd = gen_state_dict(spec_of(gg), model_seed(gn))
+                    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+                tok, msk = [torch.from_numpy(a).to(dev) for a in model_inputs(gn)]
+                y = model(tok, msk).cpu().numpy()
+                e_head = rel_errors(y[:, :96], gg["out"], gg["out_absmax"])
+                e_tail = rel_errors(y[:, 640:704], gg["out_tail"], gg["out_absmax"])
+                per[gn] = (max(e_head[0], e_tail[0]), max(e_head[1], e_tail[1]))
+            model.load_state_dict(keep, strict=True)
+            rl2, rmax = max(v[0] for v in per.values()), max(v[1] for v in per.values())
+            out["golden"] = "tests/golden/model_language*.npz (reference fp32 outputs)"
+            out["per_golden"] = {k: {"relL2": v[0], "max_abs_over_absmax": v[1]} for k, v in per.items()}
+            out["worst"] = max(per, key=lambda k: max(per[k]))
+            out["case"] = ("LanguagePerceiver B=2, three parameter / token seeds with ragged valid lengths (60 / 700, 2048 / "
+                           "333, 1 / 1290), logits rows 0..95 and 640..703; worst case gates")
         elif name == "flow":
             y = model(ins[0], ins[1]).cpu().numpy()
             rl2, rmax = rel_errors(y[:, :, ::8, ::8], g["out_sub"], g["out_absmax"])
