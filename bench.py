@@ -705,7 +705,11 @@ def main():
                 n2 = max(3, steps // 2)
                 el2 = timed_region(2, n2, eager=True)       # (the graph holds the headline policy's launches)
                 other[pol] = {"policy": pol, "value": world * B * n2 / el2, "unit": "samples/s",
-                              "ms_per_step": el2 / n2 * 1e3}
+                              "ms_per_step": el2 / n2 * 1e3, "launch": "eager"}
+                if rank == 0 and not args.no_parity:
+                    pp = parity_check(name, model, params, dev, pol)      # the same six goldens, worst case
+                    other[pol]["parity"] = {"relL2": pp["relL2"], "max_abs_over_absmax": pp["max_abs_over_absmax"],
+                                            "ok": pp["ok"]}
             model.precision_policy = policy
             class_default = other.get(dflt)
             robust = other.get("fp16sd/fp16x3f")
