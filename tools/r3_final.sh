@@ -7,7 +7,7 @@ mkdir -p gpurun_out/r3_final
 for c in language flow multimodal; do
   echo "== bench $c"; timeout -k 10 400 python bench.py --config $c > gpurun_out/r3_final/$c.json 2> gpurun_out/r3_final/$c.err || exit 1
 done
-for pol in fp16x2s fp16/fp16x3f fp16x3f/fp16x2s/fp16x3f; do
+for pol in fp16x2w fp16x2s fp16/fp16x3f; do
   tag=$(echo $pol | tr / _)
   echo "== bench language $pol"; timeout -k 10 400 python bench.py --config language --policy $pol --cpu-sample 0 > gpurun_out/r3_final/language_$tag.json 2> gpurun_out/r3_final/language_$tag.err || exit 1
 done
