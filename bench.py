@@ -515,8 +515,6 @@ def main():
 
     model, params = build_model(name, dev, policy)
     inputs = make_inputs(name, B, rank, dev)               # resident in HBM before the timed region
-    if name == "flow" and world > 1:
-        model.query_shard = (rank, world)                  # B = 1 < world: shard the decoder queries (dist.py)
     if args.hot_path_only:
         assert name == "imagenet"
         gen = torch.Generator(device="cpu").manual_seed(1000 + rank)
@@ -546,6 +544,10 @@ def main():
             parity["layernorm_fold"] = bool(fold_on) and "x3" not in split_policy(policy)[0]
         if not parity["ok"]:
             raise SystemExit(f"parity gate failed for policy {policy}: {parity}")
+    if name == "flow" and world > 1:
+        # B = 1 < world: shard the decoder queries (dist.py).  Set AFTER the gate: rank 0 runs it alone, and a sharded
+        # forward contains an all-gather the other ranks would answer from inside their warm-up steps.
+        model.query_shard = (rank, world)
 
     # The step's ~330 kernel launches replayed from ONE HIP graph (the C-ABI allocates nothing and synchronises nothing,
     # so the module forward captures: tests/test_parity_gpu.py::test_range_guard_is_deferred_and_graph_capturable): no
