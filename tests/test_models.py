@@ -51,6 +51,22 @@ def _load_generated(model, g, dev, seed=31):
     return model.to(dev).eval()
 
 
+_MODELS = {}
+
+
+def _cached_model(name, g, dev):
+    """The generated-parameter model of a golden, built once per session for the cases whose tests change nothing on it
+    but the precision policy (building + packing a LanguagePerceiver takes 6 s of a 7.5 s test)."""
+    if name not in _MODELS:
+        if len(_MODELS) >= 10:
+            _MODELS.clear()
+        _MODELS[name] = _load_generated(build(name), g, dev, model_seed(name))
+    m = _MODELS[name]
+    from perceiverio_pytorch_amd.models import DEFAULT_POLICY
+    m.precision_policy = DEFAULT_POLICY[MODEL_CASES[name]["cls"]]
+    return m
+
+
 def _close(y, ref, what, tol=TOL, absmax=None):
     y = y.detach().float().cpu().numpy().astype(np.float64)
     d = y - ref.astype(np.float64)
@@ -77,7 +93,7 @@ def test_benchmarked_path_matches_reference(name, policy):
     import perceiverio_pytorch_amd as P
     dev = torch.device("cuda:0")
     g = load(name)
-    model = _load_generated(build(name), g, dev, model_seed(name))
+    model = _cached_model(name, g, dev)
     model.precision_policy = policy
     lib = P.lib()
     tol = TOL if policy != "fp16x3" else 1e-4
@@ -179,7 +195,8 @@ def test_model_outputs_match_reference(name, policy):
         pytest.skip("the class default of the dense-output models is in the explicit list")
     if name in ("model_language_s32", "model_language_s33") and policy not in ("class default", "fp16x2w", "fp16/fp16x3f"):
         pytest.skip("extra language seeds: the shipped policies only")
-    model = _load_generated(build(name), g, dev, model_seed(name))
+    model = (_cached_model(name, g, dev) if c["cls"] == "LanguagePerceiver"
+             else _load_generated(build(name), g, dev, model_seed(name)))
     if policy != "class default":
         model.precision_policy = policy        # overrides the per-class default (models.DEFAULT_POLICY)
     else:
