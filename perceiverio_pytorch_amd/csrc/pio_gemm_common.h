@@ -11,6 +11,7 @@ struct GemmParams {
     int staged_epi;              // (gemm_nt_wide, LayerNorm-fold producer) 1: LDS-staged, row-coalesced epilogue
     int mf32;                    // (experiments build only) gemm_nt_wide fold GEMMs on the MFMA 32x32x16 variants
     int lo_n0;                   // (gemm_nt_wide only) B_lo exists for columns >= lo_n0 (multiple of 256); 0 = all
+    int k_rev;                   // (gemm_nt_wide only) odd tiles of a workgroup sweep K backwards (see its walk)
     void *C, *C_lo;
     int M, N, K;
     int64_t lda, ldb, ldc;

@@ -230,7 +230,12 @@ __global__ __launch_bounds__(256) void gemm_nt_wide(const GemmParams p, int tile
     int istep = 0, ibo = 0;
     auto issue_begin = [&]() {
         if (dj < ntl) {
-            const int kph = dph < nphK ? dph : dph - nphK;  // second sweep: the same A slices against B_lo
+            // second sweep: the same A slices against B_lo.  k_rev: the workgroup's odd tiles run the K range backwards --
+            // in the blocked walk consecutive tiles of a workgroup share their A panel, and the slices a tile used LAST
+            // are the ones still in the XCD's L2 when the next tile starts (the panel as a whole is not: a round of
+            // 8 x 4 tiles streams 6 MB through a 4 MB L2)
+            const int kph0 = dph < nphK ? dph : dph - nphK;
+            const int kph = (p.k_rev && (dj & 1)) ? nphK - 1 - kph0 : kph0;
             ia = (const char *)((const T *)p.A + kph * W_BK);
             ib = (const char *)((const T *)p.B + (dph < nphK ? 0 : p.dB1) + kph * W_BK);
             isb = smem + dslot * W_STAGE + wave * 4096;
@@ -993,8 +998,13 @@ void gemm_wide_launch(const GemmParams &p, int dtype, hipStream_t s) {
     const int tiles_m = (p.M + W_BM - 1) / W_BM, tiles_n = (p.n_store + W_BN - 1) / W_BN;
     const int G = wide_grid((int64_t)tiles_m * tiles_n);
     dim3 grid((unsigned)G, 1, 1), block(256, 1, 1);
+    GemmParams pk = p;
+    {
+        const char *e = getenv("PIO_WIDE_KREV");  // (read per launch: A/B switch for tools/ab_env.py)
+        pk.k_rev = e ? atoi(e) : 0;
+    }
 #define PIO_WK(DTV, ACT, OUT, R, LNF) \
-    hipLaunchKernelGGL((gemm_nt_wide<DTV, ACT, OUT, R, LNF>), grid, block, 0, s, p, tiles_m, tiles_n)
+    hipLaunchKernelGGL((gemm_nt_wide<DTV, ACT, OUT, R, LNF>), grid, block, 0, s, pk, tiles_m, tiles_n)
     // MFMA 32x32x16 variants of the fold GEMMs (template parameter MF): an experiment that measured level -- 7 % fewer
     // cycles, 5 % less clock (DESIGN_LOG.md) -- instantiated in the experiments build only (-DPIO_EXPERIMENTS).
 #ifdef PIO_EXPERIMENTS
@@ -1008,7 +1018,7 @@ void gemm_wide_launch(const GemmParams &p, int dtype, hipStream_t s) {
     const bool mf_prod = mf_any && whole && p.row_part && p.R16_hi && !p.C && p.X16_lo && p.staged_epi &&
                          (int64_t)tiles_m * tiles_n <= G;
 #define PIO_WKM(DTV, ACT, OUT, R, LNF) \
-    hipLaunchKernelGGL((gemm_nt_wide<DTV, ACT, OUT, R, LNF, 1>), grid, block, 0, s, p, tiles_m, tiles_n)
+    hipLaunchKernelGGL((gemm_nt_wide<DTV, ACT, OUT, R, LNF, 1>), grid, block, 0, s, pk, tiles_m, tiles_n)
 #else
     const bool mf_cons = false, mf_prod = false;
 #define PIO_WKM(DTV, ACT, OUT, R, LNF) ((void)0)
