@@ -52,8 +52,11 @@ SEED = 31                    # parameter seed of the committed whole-model golde
 CONFIGS = {
     "imagenet": dict(golden="model_classify_conv", parity_golden="model_classify_b4_s31",
                      # the gate runs on EVERY B = 4 reference golden (five seeds + natural-image statistics), worst case reported
+                     # + (round 4) two goldens with TRAINED-LIKE parameter statistics: log-normal weight-row scales over a
+                     # decade, LayerNorm gains in [0.2, 5], outlier channels (oracle/cases.py gen_state_dict(stats="trained"))
                      parity_goldens=["model_classify_b4_s31", "model_classify_b4_s32", "model_classify_b4_s33",
-                                     "model_classify_b4_s34", "model_classify_b4_s35", "model_classify_b4_natural"],
+                                     "model_classify_b4_s34", "model_classify_b4_s35", "model_classify_b4_natural",
+                                     "model_classify_b4_trained1", "model_classify_b4_trained2"],
                      # "fp16sd": single-sweep fp16 with error-feedback rounding of the weights the 8 blocks share (one packed
                      # image set per block; same kernels and time as "fp16", worst golden 6.6e-4 / 7.3e-4 against 7.7e-4 /
                      # 8.2e-4 -- runtime.py _POLICIES, tools/sd_parity.py)
@@ -184,13 +187,13 @@ def parity_check(name, model, params, dev, policy):
     with torch.inference_mode():
         if name == "imagenet":
             # every B = 4 golden: the parameters of a golden are those of ITS seed (the timed model keeps seed 31's)
-            from cases import gen_state_dict, model_seed
+            from cases import gen_state_dict, model_seed, model_stats
             per = {}
             keep = {k: v.clone() for k, v in model.state_dict().items()}
             for gn in CONFIGS[name]["parity_goldens"]:
                 gg = np.load(os.path.join(ROOT, "tests", "golden", gn + ".npz"))
-                if model_seed(gn) != SEED:
-                    sd = gen_state_dict(spec_of(gg), model_seed(gn))
+                if model_seed(gn) != SEED or model_stats(gn):
+                    sd = gen_state_dict(spec_of(gg), model_seed(gn), model_stats(gn))
                     model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
                 # the golden's 4 images three times over: B = 12 is 6144 latent rows, where the LayerNorm fold of the
                 # timed batch engages (pio_ln_fold_enable: automatic from 6144 rows); every copy is held to the golden
@@ -205,7 +208,8 @@ def parity_check(name, model, params, dev, policy):
             out["worst"] = worst
             out["case"] = ("ClassificationPerceiver B=4 goldens x 3 copies (6144 latent rows: same LayerNorm-fold path as the timed "
                            "batch), "
-                           "5 parameter/input seeds + natural-image statistics; worst case gates")
+                           "5 parameter/input seeds + natural-image statistics + 2 with trained-like parameter statistics; "
+                           "worst case gates")
         elif name == "language":
             # three goldens (parameter / token seeds 31 / 32 / 33, different ragged lengths): worst case gates
             from cases import gen_state_dict, model_seed
@@ -229,25 +233,55 @@ def parity_check(name, model, params, dev, policy):
             out["case"] = ("LanguagePerceiver B=2, three parameter / token seeds with ragged valid lengths (60 / 700, 2048 / "
                            "333, 1 / 1290), logits rows 0..95 and 640..703; worst case gates")
         elif name == "flow":
-            y = model(ins[0], ins[1]).cpu().numpy()
-            rl2, rmax = rel_errors(y[:, :, ::8, ::8], g["out_sub"], g["out_absmax"])
-            out["case"] = "FlowPerceiver full size, 8x sub-sampled flow field"
+            # two goldens (parameter / frame seeds 31 and 32): worst case gates
+            from cases import gen_state_dict, model_seed, model_stats
+            per = {}
+            keep = {k: v.clone() for k, v in model.state_dict().items()}
+            for gn in ("model_flow_full", "model_flow_full_s32"):
+                gg = np.load(os.path.join(ROOT, "tests", "golden", gn + ".npz"))
+                if model_seed(gn) != SEED:
+                    sd = gen_state_dict(spec_of(gg), model_seed(gn), model_stats(gn))
+                    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+                i1, i2 = [torch.from_numpy(a).to(dev) for a in model_inputs(gn)]
+                y = model(i1, i2).cpu().numpy()
+                per[gn] = rel_errors(y[:, :, ::8, ::8], gg["out_sub"], gg["out_absmax"])
+            model.load_state_dict(keep, strict=True)
+            rl2, rmax = max(v[0] for v in per.values()), max(v[1] for v in per.values())
+            out["golden"] = "tests/golden/model_flow_full*.npz (reference fp32 outputs)"
+            out["per_golden"] = {k: {"relL2": v[0], "max_abs_over_absmax": v[1]} for k, v in per.items()}
+            out["worst"] = max(per, key=lambda k: max(per[k]))
+            out["case"] = "FlowPerceiver full size, 8x sub-sampled flow field, two parameter / frame seeds; worst case gates"
         else:
-            c = MODEL_CASES[gname]
-            images, audio = ins
-            b, t, ch, h, w = images.shape
-            k = c["chunks"][0]
-            ics = t * h * w // c["n_chunks"]
-            acs = audio.shape[1] // model.audio_samples_per_patch // c["n_chunks"]
-            sub = {"image": torch.arange(ics * k, ics * (k + 1)), "audio": torch.arange(acs * k, acs * (k + 1)),
-                   "label": None}
+            # two goldens (parameter / input seeds 31 and 32), the first frozen output chunk of each: worst case gates
+            from cases import gen_state_dict, model_seed, model_stats
             from perceiverio_pytorch_amd.models import _policy_scope
-            with _policy_scope(model):
-                o = model.perceiver({"image": images, "audio": audio,
-                                     "label": torch.zeros((b, model.num_classes), device=dev)},
-                                    subsampled_output_points=sub)
-            rl2, rmax = rel_errors(o["image"].cpu().numpy(), g[f"out_image_{k}"])
-            out["case"] = "MultiModalPerceiver full size, output chunk 0 of 128 (image reconstruction rows)"
+            per = {}
+            keep = {k: v.clone() for k, v in model.state_dict().items()}
+            for gn in ("model_multimodal_full", "model_multimodal_full_s32"):
+                gg = np.load(os.path.join(ROOT, "tests", "golden", gn + ".npz"))
+                c = MODEL_CASES[gn]
+                if model_seed(gn) != SEED:
+                    sd = gen_state_dict(spec_of(gg), model_seed(gn), model_stats(gn))
+                    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+                images, audio = [torch.from_numpy(a).to(dev) for a in model_inputs(gn)]
+                b, t, ch, h, w = images.shape
+                k = c["chunks"][0]
+                ics = t * h * w // c["n_chunks"]
+                acs = audio.shape[1] // model.audio_samples_per_patch // c["n_chunks"]
+                sub = {"image": torch.arange(ics * k, ics * (k + 1)), "audio": torch.arange(acs * k, acs * (k + 1)),
+                       "label": None}
+                with _policy_scope(model):
+                    o = model.perceiver({"image": images, "audio": audio,
+                                         "label": torch.zeros((b, model.num_classes), device=dev)},
+                                        subsampled_output_points=sub)
+                per[gn] = rel_errors(o["image"].cpu().numpy(), gg[f"out_image_{k}"])
+            model.load_state_dict(keep, strict=True)
+            rl2, rmax = max(v[0] for v in per.values()), max(v[1] for v in per.values())
+            out["golden"] = "tests/golden/model_multimodal_full*.npz (reference fp32 outputs)"
+            out["per_golden"] = {k: {"relL2": v[0], "max_abs_over_absmax": v[1]} for k, v in per.items()}
+            out["worst"] = max(per, key=lambda k: max(per[k]))
+            out["case"] = ("MultiModalPerceiver full size, one output chunk of 128 (image reconstruction rows), two parameter / "
+                           "input seeds; worst case gates")
     out.update(relL2=rl2, max_abs_over_absmax=rmax, ok=bool(rl2 <= 1e-3 and rmax <= 1e-3))
     return out
 
@@ -596,7 +630,7 @@ def main():
         else:
             out = forward(*inputs)
         if world > 1 and name == "imagenet":
-            out = all_gather_rows(out)                     # the path's only collective (RCCL over xGMI): [B*W, 1000]
+            out = all_gather_rows(out, reuse_buffer=True)  # the path's only collective (RCCL over xGMI): [B*W, 1000]
         return out
 
     def sync():

@@ -255,10 +255,10 @@ typedef struct pio_gemm_t {
     int32_t out_f32;
     int32_t n_store;
     int32_t dtype;
-    /* LayerNorm folded into the GEMMs around it (optional; kernel gemm_nt_wide only, else PIO_E_SHAPE).
-     * Producer (fp32 out): X16 receives a 16-bit copy of the result (row stride ld16) and row_part, [M][N/128][2]
-     * fp32, the (sum, sum of squares) of every result row over each 128-column block (N % 128 == 0).
-     * Consumer (16-bit out, K == 1024): ln_part is the row_part a producer wrote for this GEMM's A operand and
+    /* LayerNorm folded into the GEMMs around it (optional; a shape neither fold kernel takes: PIO_E_SHAPE).
+     * Producer (fp32 out): X16 receives a 16-bit copy of the result (row stride ld16) and row_part, [M][N/w][2]
+     * fp32, the (sum, sum of squares) of every result row over each w-column slot (w = row_slot_w below).
+     * Consumer (16-bit out): ln_part is the row_part a producer wrote for this GEMM's A operand and
      * ln_c[n] = sum_k B[n,k]; the result is rstd_m * (A B^T)[m,n] - rstd_m * mean_m * ln_c[n] + bias[n] [GELU], i.e.
      * LayerNorm(x) W^T + b for B = W * gamma, bias = W beta + b (transformer_primitives.py:281-292). */
     void *X16;
@@ -277,6 +277,13 @@ typedef struct pio_gemm_t {
     int32_t b_lo_n0;
     /* LayerNorm-fold producer only (optional): *range_flag |= 1 when a row's (sum, sum of squares) is not finite */
     int32_t *range_flag;
+    /* Slot form of the row statistics.  Producer: row_slot_w = columns per (sum, sum of squares) slot of row_part,
+     * [M][N / row_slot_w][2]: 0 or 128 = the 256x256-tile kernel (gemm_nt_wide: N % 128 == 0), 64 = the 128 / 64-tile
+     * kernel (stacks of fewer rows than the wide kernel takes; N % 64 == 0, residual and result as 16-bit pairs).
+     * Consumer: ln_slots = slots per row of ln_part (0 = K / 128).  K / 128 slots, K % 128 == 0, K <= 1536 and
+     * M >= 2048 run on gemm_nt_wide, anything else on the tile kernel. */
+    int32_t ln_slots;
+    int32_t row_slot_w;
 } pio_gemm_t;
 int pio_gemm_nt(const pio_gemm_t *g, void *stream);
 
@@ -303,6 +310,17 @@ size_t pio_mlp_workspace_bytes(const pio_mlp_t *m, int64_t rows);
 int pio_mlp_fwd(const pio_mlp_t *m, const pio_tensor3_t *x, float *out, void *workspace,
                 size_t workspace_bytes, void *stream);
 
+/* Per-call options of the *_opts entry points (NULL or all zero = the library defaults).  They replace, call by call
+ * and thread by thread, the process-wide switches pio_ln_fold_enable / pio_set_cu_budget (which stay as test / A-B
+ * overrides): two threads driving two encoders on two devices never see each other's choice.
+ *   ln_fold:   0 = process-wide setting, 1 = LayerNorm fold off (the range guard's un-folded repeat), 2 = where it pays,
+ *              3 = wherever a block offers it
+ *   cu_budget: CUs the persistent GEMM kernels size their grids for (a CU-masked stream's share); 0 = process-wide */
+typedef struct pio_call_opts_t {
+    int32_t ln_fold;
+    int32_t cu_budget;
+} pio_call_opts_t;
+
 /* SelfAttention.forward (transformer_primitives.py:275-297), no mask (perceiver.py:106 never passes one;
  * masks, attention_bias [B,H,N,N] and probs_out [B,H,N,N] (return_matrix) are accepted for interface
  * parity, all optional).  out [B,N,D] fp32 contiguous; out may alias x.data when x is contiguous. */
@@ -310,6 +328,11 @@ size_t pio_self_attention_workspace_bytes(const pio_self_attention_t *s, int32_t
 int pio_self_attention_fwd(const pio_self_attention_t *s, const pio_tensor3_t *x, const uint8_t *kv_mask,
                            const uint8_t *q_mask, const uint8_t *full_mask, const float *attention_bias,
                            float *out, float *probs_out, void *workspace, size_t workspace_bytes, void *stream);
+
+int pio_self_attention_fwd_opts(const pio_self_attention_t *s, const pio_tensor3_t *x, const uint8_t *kv_mask,
+                                const uint8_t *q_mask, const uint8_t *full_mask, const float *attention_bias,
+                                float *out, float *probs_out, void *workspace, size_t workspace_bytes, void *stream,
+                                const pio_call_opts_t *opts);
 
 /* CrossAttention.forward (transformer_primitives.py:371-406). out [B,Tq,q_in] fp32 contiguous. */
 size_t pio_cross_attention_workspace_bytes(const pio_cross_attention_t *c, int32_t B, int32_t Tq, int32_t Tk);
@@ -348,6 +371,13 @@ int pio_encoder_fwd_blocks(const pio_cross_attention_t *cross, const pio_self_at
                            int32_t num_blocks, int32_t per_block, const pio_tensor3_t *inputs,
                            const pio_tensor3_t *inputs_tail, const pio_tensor3_t *latents, const uint8_t *input_mask,
                            float *out, void *workspace, size_t workspace_bytes, void *stream);
+
+/* pio_encoder_fwd_blocks with per-call options (opts == NULL: the same call). */
+int pio_encoder_fwd_opts(const pio_cross_attention_t *cross, const pio_self_attention_t *layers, int32_t L,
+                         int32_t num_blocks, int32_t per_block, const pio_tensor3_t *inputs,
+                         const pio_tensor3_t *inputs_tail, const pio_tensor3_t *latents, const uint8_t *input_mask,
+                         float *out, void *workspace, size_t workspace_bytes, void *stream,
+                         const pio_call_opts_t *opts);
 
 /* PerceiverDecoder.forward (perceiver.py:166-180): cross-attend(query <- latents, query mask) and the
  * optional final nn.Linear (final == NULL => final_project=False).  out [B,Q,out_channels] fp32. */

@@ -65,14 +65,35 @@ def encdec_kwargs(cfg, im=None, qm=None):
 # ---------------------------------------------------------------------------------------------------
 # whole-model cases ("next" rows of SURVEY.md 8f): parameters for an arbitrary state_dict spec
 # ---------------------------------------------------------------------------------------------------
-def gen_state_dict(spec, seed):
+def gen_state_dict(spec, seed, stats=None):
     """spec: iterable of (name, shape).  Deterministic, non-trivial values for every entry kind that occurs in the
-    reference's models (weights ~ fan-in scaled, biases / LayerNorm / BatchNorm statistics perturbed)."""
+    reference's models (weights ~ fan-in scaled, biases / LayerNorm / BatchNorm statistics perturbed).
+
+    stats="trained": parameter statistics of a TRAINED checkpoint instead of an initialiser's -- the rows of every
+    nn.Linear weight scaled by a log-normal factor spanning about a decade (sigma = ln(10) / 4, mean square kept), three
+    outlier input channels per wide Linear (x 6), LayerNorm gains log-uniform in [0.2, 5] with biases N(0, 0.3).  Heavy-
+    tailed rows and large LayerNorm gains are what the fp16 operand rounding and the LayerNorm fold (weights x gamma) are
+    most sensitive to; a truncated-normal initialisation has neither."""
     out = {}
     for name, shape in spec:
         shape = tuple(int(s) for s in shape)
         leaf = name.rsplit(".", 1)[-1]
         rng = O._rng_for(name, seed)
+        if stats == "trained" and "layer_norm" in name and len(shape) == 1:
+            if leaf == "weight":
+                out[name] = np.exp(rng.uniform(np.log(0.2), np.log(5.0), shape)).astype(np.float32)
+            else:
+                out[name] = (0.3 * rng.standard_normal(shape)).astype(np.float32)
+            continue
+        if stats == "trained" and leaf == "weight" and len(shape) == 2 and ".embed." not in name \
+                and not name.endswith("_embedding.weight"):
+            w = np.clip(rng.standard_normal(shape), -2.0, 2.0) / 0.87962566103423978 / np.sqrt(shape[1])
+            srow = np.exp((np.log(10.0) / 4.0) * rng.standard_normal(shape[0]))
+            w = w * (srow / np.sqrt(np.mean(srow * srow)))[:, None]
+            if shape[1] >= 256:
+                w[:, rng.choice(shape[1], 3, replace=False)] *= 6.0
+            out[name] = w.astype(np.float32)
+            continue
         if leaf == "num_batches_tracked":
             out[name] = np.zeros(shape, dtype=np.int64)
         elif leaf == "running_mean":
@@ -130,6 +151,17 @@ MODEL_CASES = {
     # full-size multimodal auto-encoder (BASELINE config 5): 16 x 224 x 224 video + 30720 audio samples + label,
     # M = 52 097 x 704, 784 x 512 latents; output chunks 0 and 127 of n_chunks = 128 (6272 + 15 + 1 queries each)
     "model_multimodal_full": dict(cls="MultiModalPerceiver", kw=dict(), batch=1, chunks=(0, 127), n_chunks=128),
+    # round 4: what the headline margin is measured on, widened --
+    # two B = 4 classifier goldens with TRAINED-LIKE parameter statistics (gen_state_dict(stats="trained"): log-normal row
+    # scales over a decade, LayerNorm gains in [0.2, 5], outlier channels), one on N(0,1) pixels, one on natural-image inputs
+    "model_classify_b4_trained1": dict(cls="ClassificationPerceiver", kw=dict(prep="FOURIER_POS_CONVNET"), batch=4,
+                                       pseed=41, stats="trained"),
+    "model_classify_b4_trained2": dict(cls="ClassificationPerceiver", kw=dict(prep="FOURIER_POS_CONVNET"), batch=4,
+                                       pseed=42, stats="trained", inputs="natural"),
+    # ... and a second parameter / input seed for each dense-output model at full size
+    "model_flow_full_s32": dict(cls="FlowPerceiver", kw=dict(), batch=1, pseed=32),
+    "model_multimodal_full_s32": dict(cls="MultiModalPerceiver", kw=dict(), batch=1, chunks=(3, 77), n_chunks=128,
+                                      pseed=32),
 }
 
 
@@ -171,6 +203,11 @@ def model_seed(name):
     return MODEL_CASES[name].get("pseed", 31)
 
 
+def model_stats(name):
+    """gen_state_dict's `stats` argument of a MODEL_CASES entry (None = initialiser-like parameters)."""
+    return MODEL_CASES[name].get("stats")
+
+
 def model_inputs(name, seed=None):
     """Seeded inputs of a MODEL_CASES entry as numpy arrays (dict of forward kwargs / positional list)."""
     c = MODEL_CASES[name]
@@ -189,7 +226,7 @@ def model_inputs(name, seed=None):
         tok[~mask] = 0
         return [tok, mask]
     if c["cls"] == "FlowPerceiver":
-        hw = (368, 496) if name == "model_flow_full" else (60, 80)
+        hw = (368, 496) if name.startswith("model_flow_full") else (60, 80)
         return [_rand(name + "i1", (B, 3) + hw, seed), _rand(name + "i2", (B, 3) + hw, seed)]
     if c["cls"] == "MultiModalPerceiver":
         kw = dict(num_frames=16, img_size=(224, 224), audio_samples_per_frame=48000 // 25)

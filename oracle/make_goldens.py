@@ -305,7 +305,7 @@ if __name__ == "__main__" and not (sys.argv[1:] and all(a.startswith("model_") f
 # whole models ("next" rows): reference task models with generated parameters -> outputs
 # ------------------------------------------------------------------------------------
 def case_models(only=None):
-    from cases import MODEL_CASES, gen_state_dict, model_inputs, model_seed
+    from cases import MODEL_CASES, gen_state_dict, model_inputs, model_seed, model_stats
     from perceiver_io.classification_perceiver import ClassificationPerceiver, PrepType
     from perceiver_io.flow_perceiver import FlowPerceiver
     from perceiver_io.language_perceiver import LanguagePerceiver
@@ -321,7 +321,7 @@ def case_models(only=None):
                      "MultiModalPerceiver": MultiModalPerceiver}[c["cls"]](**kw)
         sd = model.state_dict()
         spec = [(k, tuple(v.shape)) for k, v in sd.items()]
-        params = gen_state_dict(spec, model_seed(name))
+        params = gen_state_dict(spec, model_seed(name), model_stats(name))
         model.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
         model.eval()
         ins = model_inputs(name)
@@ -329,7 +329,7 @@ def case_models(only=None):
         save = dict(spec_names=np.array([k for k, _ in spec]),
                     spec_shapes=np.array([",".join(str(d) for d in s) for _, s in spec]))
         with torch.inference_mode():
-            if name == "model_flow_full":
+            if name.startswith("model_flow_full"):
                 out = model(tin[0], tin[1]).numpy()                      # [1, 2, 368, 496]
                 save.update(out_sub=out[:, :, ::8, ::8], out_absmax=np.array(np.abs(out).max()),
                             out_l2=np.array(np.sqrt((out.astype(np.float64) ** 2).sum())))
@@ -339,7 +339,7 @@ def case_models(only=None):
                 out_test = model(tin[0], tin[1], test_mode=True, min_overlap=10).numpy()
                 save.update(out_train=out_train, out_test=out_test)
                 print(f"{name:42s} train {out_train.shape} test {out_test.shape}")
-            elif name == "model_multimodal_full":
+            elif name.startswith("model_multimodal_full"):
                 # single output chunks of the reference's loop (multimodal_perceiver.py:146-157): the perceiver call
                 # the reference makes for chunk k, nothing else
                 images, audio = tin

@@ -66,6 +66,11 @@ class Tensor3(C.Structure):
                 ("T", C.c_int32), ("C", C.c_int32)]
 
 
+class CallOpts(C.Structure):
+    """pio_call_opts_t: per-call (thread-local inside the library) LayerNorm-fold mode and CU budget."""
+    _fields_ = [("ln_fold", C.c_int32), ("cu_budget", C.c_int32)]
+
+
 class Gemm(C.Structure):
     _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("A_lo", C.c_void_p), ("B_lo", C.c_void_p), ("C", C.c_void_p),
                 ("C_lo", C.c_void_p),
@@ -81,7 +86,7 @@ class Gemm(C.Structure):
                 ("X16", C.c_void_p), ("ld16", C.c_int64), ("row_part", C.c_void_p), ("ln_part", C.c_void_p),
                 ("ln_c", C.c_void_p), ("ln_eps", C.c_float),
                 ("X16_lo", C.c_void_p), ("R16_hi", C.c_void_p), ("R16_lo", C.c_void_p), ("b_lo_n0", C.c_int32),
-                ("range_flag", C.c_void_p)]
+                ("range_flag", C.c_void_p), ("ln_slots", C.c_int32), ("row_slot_w", C.c_int32)]
 
 
 # name -> (restype, argtypes); must list EVERY function declared in include/pio_hip.h
@@ -115,6 +120,8 @@ SIGNATURES = {
     "pio_mlp_fwd": (C.c_int, [P(Mlp), P(Tensor3), _vp, _vp, _sz, _vp]),
     "pio_self_attention_workspace_bytes": (_sz, [P(SelfAttention), _i32, _i32]),
     "pio_self_attention_fwd": (C.c_int, [P(SelfAttention), P(Tensor3), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "pio_self_attention_fwd_opts": (C.c_int, [P(SelfAttention), P(Tensor3), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp,
+                                              P(CallOpts)]),
     "pio_cross_attention_workspace_bytes": (_sz, [P(CrossAttention), _i32, _i32, _i32]),
     "pio_cross_attention_fwd": (C.c_int, [P(CrossAttention), P(Tensor3), P(Tensor3), _vp, _vp, _vp, _vp, _vp, _vp,
                                           _vp, _sz, _vp]),
@@ -125,6 +132,8 @@ SIGNATURES = {
                                         P(Tensor3), _vp, _vp, _vp, _sz, _vp]),
     "pio_encoder_fwd_blocks": (C.c_int, [P(CrossAttention), P(SelfAttention), _i32, _i32, _i32, P(Tensor3), P(Tensor3),
                                          P(Tensor3), _vp, _vp, _vp, _sz, _vp]),
+    "pio_encoder_fwd_opts": (C.c_int, [P(CrossAttention), P(SelfAttention), _i32, _i32, _i32, P(Tensor3), P(Tensor3),
+                                       P(Tensor3), _vp, _vp, _vp, _sz, _vp, P(CallOpts)]),
     "pio_decoder_workspace_bytes": (_sz, [P(CrossAttention), P(Linear), _i32, _i32, _i32]),
     "pio_decoder_fwd": (C.c_int, [P(CrossAttention), P(Linear), _i32, P(Tensor3), P(Tensor3), _vp, _vp, _vp, _sz,
                                   _vp]),

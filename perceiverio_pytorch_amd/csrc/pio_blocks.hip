@@ -76,6 +76,9 @@ struct LnFold {
     void *out16_lo = nullptr;
     const void *res16_hi = nullptr, *res16_lo = nullptr;
     int32_t *range_flag = nullptr;  // producer: the caller's range-guard word (pio_ln_fold_t.range_flag)
+    // slot form of the row statistics (pio_gemm_t.ln_slots / row_slot_w): 128-column slots = the 256 x 256-tile kernel,
+    // 64-column slots = the tile kernels (stacks of fewer rows)
+    int in_slots = 0, slot_w = 0;
 };
 
 // y[rows, n] = x16[rows, lin.k] * W^T (+bias) (act) (+R); a 16-bit output has ldc = lin.n (padded).
@@ -88,6 +91,7 @@ static int linear_fwd(const pio_linear_t &lin_plain, int dtype, Pair x, int64_t 
         g.ln_part = fold->in_part;
         g.ln_c = fold->c;
         g.ln_eps = fold->eps;
+        g.ln_slots = fold->in_slots;
     }
     if (fold && fold->out16) {
         g.X16 = fold->out16;
@@ -97,6 +101,7 @@ static int linear_fwd(const pio_linear_t &lin_plain, int dtype, Pair x, int64_t 
         g.R16_hi = fold->res16_hi;
         g.R16_lo = fold->res16_lo;
         g.range_flag = fold->range_flag;
+        g.row_slot_w = fold->slot_w;
     }
     g.A = x.hi;
     g.A_lo = x.lo;
@@ -230,25 +235,26 @@ static int attention_core(const pio_attention_t &a, Pair xq, bool q_bcast, Pair 
 
     // 0: the fully fused self-attention form: ONE GEMM over the stacked [q | k | v] weight image, then the fused
     //    attention kernel reading V row-major (transposed LDS reads).  Needs: same input for q, k and v, single-
-    //    sweep operands everywhere, 128-wide heads, nothing that wants the score matrix, and the q16 | k16 | vt16
-    //    scratch regions adjacent so that they form one [rows, 3*H*128] matrix.
+    //    sweep operands everywhere, head widths the fused kernel covers, nothing that wants the score matrix, and the
+    //    q16 | k16 | vt16 scratch regions holding one [rows, H*(2 dk + dv)] matrix.
     {
-        const size_t third = (size_t)B * Tq * hdk * 2;
+        const int64_t ld3 = 2 * hdk + ldo;  // one row of [q | k | v]
         // (a q|k|v image whose V rows alone carry a lo half -- policies "x2s" / "x2w" -- is taken only inside the
         //  LayerNorm fold, where the wide GEMM kernel, which honours pio_linear_t.lo_row0, is guaranteed)
         const pio_linear_t &qkv_used = (fold_in && fold_in->in_part) ? *fold_in->w : a.qkv;
         const bool qkv_lo_ok = !qkv_used.w_lo || (fold_in && fold_in->in_part && qkv_used.lo_row0 == 2 * hdk);
         const bool fuse_qkv = a.qkv.w_hi && qkv_lo_ok && !a.act_split && !q_bcast && xq.hi == xk.hi &&
-                              xk.hi == xv.hi && Tq == Tk && a.dkp == 128 && a.dvp == 128 && a.qkv.n == 3 * hdk &&
+                              xk.hi == xv.hi && Tq == Tk && flash_supported(a.dkp, a.dvp) && a.qkv.n == ld3 &&
                               !kv_mask && !q_mask && !full_mask && !attention_bias && !probs_out &&
-                              (char *)w.k16.hi == (char *)w.q16.hi + third &&
-                              (char *)w.vt16.hi == (char *)w.k16.hi + third;
+                              // (q16, k16, vt16 are consecutive carves: together they hold the [rows, ld3] matrix)
+                              (char *)w.q16.hi < (char *)w.k16.hi && (char *)w.k16.hi < (char *)w.vt16.hi &&
+                              (size_t)((char *)w.vt16.hi - (char *)w.q16.hi) + (size_t)B * ldo * tkv * 2 >=
+                                  (size_t)B * Tq * ld3 * 2;
         if (fuse_qkv) {
-            const int64_t ld3 = 3 * hdk;
             PIO_TRY(linear_fwd(a.qkv, a.dtype, xq, (int64_t)B * Tq, w.q16.hi, nullptr, false, 0, ld3, 0, nullptr, s,
                                fold_in));
             const char *base = (const char *)w.q16.hi;
-            PIO_TRY(flash_attention_launch(a.dtype, 128, 128, a.dk, base, base + hdk * 2, base + 2 * hdk * 2,
+            PIO_TRY(flash_attention_launch(a.dtype, a.dkp, a.dvp, a.dk, base, base + hdk * 2, base + 2 * hdk * 2,
                                            w.o16.hi, B, H, Tq, Tk, ld3, ld3, ld3, ldo, (int64_t)Tq * ld3,
                                            (int64_t)Tk * ld3, (int64_t)Tk * ld3, (int64_t)Tq * ldo, true, s));
             return linear_fwd(a.o, a.dtype, w.o16, (int64_t)B * Tq, out, nullptr, true, a.out, out_ld, 0, res, s,
@@ -492,8 +498,8 @@ struct SelfPlan {
             x16b = inplace ? x16.hi : c.take((size_t)rows * cmax * 2);
             lo_a = c.take((size_t)rows * cmax * 2);
             lo_b = inplace ? lo_a : c.take((size_t)rows * cmax * 2);
-            part_a = (float *)c.take((size_t)rows * 8 * 2 * 4);
-            part_b = (float *)c.take((size_t)rows * 8 * 2 * 4);
+            part_a = (float *)c.take((size_t)rows * (cmax / 64 + 1) * 2 * 4);  // (up to one slot per 64 columns)
+            part_b = (float *)c.take((size_t)rows * (cmax / 64 + 1) * 2 * 4);
             if (inplace && !sa.mlp.act_split && !sa.attn.act_split &&
                 (size_t)rows * padc(sa.mlp.hidden) <= (size_t)rows * sa.attn.heads * sa.attn.dvp)
                 h16.hi = core.o16.hi;
@@ -508,7 +514,7 @@ struct SelfPlan {
 // measured on the ImageNet classifier (tools/latency_probe.py, ms per forward, fold on / off): B=4 7.75 / 5.22,
 // B=8 8.12 / 7.64, B=12 10.14 / 10.09, B=16 10.69 / 11.57, B=32 16.62 / 18.24 -- hence 6144 rows (env
 // PIO_LN_FOLD_MIN_ROWS).
-static int &ln_fold_choice() {
+static int &ln_fold_global() {
     static int choice = [] {
         const char *e = getenv("PIO_LN_FOLD");
         const int v = e ? atoi(e) : 1;
@@ -516,8 +522,26 @@ static int &ln_fold_choice() {
     }();
     return choice;
 }
+// Per-call override (pio_call_opts_t.ln_fold of the *_opts entry points: 1 = off, 2 = where it pays, 3 = wherever
+// offered; 0 = the process-wide setting above): thread-local for the duration of the call, so that two threads driving
+// two encoders never see each other's choice.
+static thread_local int tl_ln_fold = 0;
+static int ln_fold_choice() { return tl_ln_fold > 0 ? tl_ln_fold - 1 : ln_fold_global(); }
+struct CallOpts {  // RAII around one C-ABI call
+    int prev_fold, prev_cu;
+    explicit CallOpts(const pio_call_opts_t *o) : prev_fold(tl_ln_fold), prev_cu(cu_budget_call(-1)) {
+        if (o) {
+            tl_ln_fold = (o->ln_fold >= 0 && o->ln_fold <= 3) ? o->ln_fold : 0;
+            cu_budget_call(o->cu_budget > 0 ? o->cu_budget : 0);
+        }
+    }
+    ~CallOpts() {
+        tl_ln_fold = prev_fold;
+        cu_budget_call(prev_cu);
+    }
+};
 int ln_fold_enable(int on) {
-    int &c = ln_fold_choice();
+    int &c = ln_fold_global();
     const int prev = c;
     c = on < 0 ? 0 : on > 2 ? 2 : on;
     return prev;
@@ -530,6 +554,16 @@ static int64_t ln_fold_min_rows() {
         return (int64_t)(v < 2048 ? 2048 : v);
     }();
     return ln_fold_choice() == 2 ? 2048 : auto_rows;
+}
+// Below that row count the fold runs on the tile kernels (64-column statistics slots) -- from this many rows on
+// (env PIO_LN_FOLD_SMALL_MIN_ROWS; mode 2: from 128 rows).
+static int64_t ln_fold_small_min_rows() {
+    static const int64_t auto_rows = [] {
+        const char *e = getenv("PIO_LN_FOLD_SMALL_MIN_ROWS");
+        const long long v = e ? atoll(e) : 512;
+        return (int64_t)(v < 128 ? 128 : v);
+    }();
+    return ln_fold_choice() == 2 ? 128 : auto_rows;
 }
 
 // Carried from one SelfAttention block to the next inside a stack: the 16-bit copy and the partial sums of the block's
@@ -550,26 +584,33 @@ static int self_attention_run(const pio_self_attention_t &sa, const pio_tensor3_
     if (x.C != sa.attn.q_in || sa.attn.k_in != x.C || sa.attn.v_in != x.C || sa.attn.out != x.C ||
         sa.mlp.in != x.C || sa.mlp.out != x.C)
         return PIO_E_SHAPE;  // residual adds need matching widths (the reference raises a RuntimeError)
-    // LayerNorm fold: 1024-channel contiguous rows, single-sweep operands, the fused q|k|v form, enough rows for the
-    // 256x256-tile kernel to fill the chip, nothing that needs the score matrix
-    // (weights may be (hi, lo) pairs -- policies "x2s" / "x2w": the wide kernel runs a second K sweep against the lo
-    //  image; of the stacked q|k|v image only the V rows may have one.  Activations single-sweep.)
-    const bool fold = ln_fold_enabled() && p.x16b && x.C == 1024 && rows >= ln_fold_min_rows() && x.stride_t == x.C &&
-                      (B == 1 || x.stride_b == (int64_t)N * x.C) && !sa.attn.act_split && !sa.mlp.act_split &&
-                      sa.attn.qkv.w_hi && (!sa.fold.qkv.w_lo || sa.fold.qkv.lo_row0 == 2 * sa.attn.heads * sa.attn.dkp) &&
-                      (!sa.fold.fc1.w_lo || sa.fold.fc1.lo_row0 == 0) &&
-                      sa.attn.dkp == 128 && sa.attn.dvp == 128 && sa.fold.qkv.n == sa.attn.qkv.n &&
-                      sa.fold.qkv.k == 1024 && sa.fold.fc1.k == 1024 && sa.fold.fc1.n == sa.mlp.fc1.n &&
-                      sa.mlp.dtype == sa.attn.dtype && !kv_mask && !q_mask && !full_mask && !attention_bias &&
-                      !probs_out && (((uintptr_t)x.data) & 15) == 0;
+    // LayerNorm fold: contiguous rows of 512 / 768 / 1024 / 1280 / 1536 channels, single-sweep activations, the fused
+    // q|k|v form (head widths the fused attention kernel covers), nothing that needs the score matrix.  Two kernel
+    // families: the 256 x 256-tile kernel with 128-column statistics slots for stacks with enough rows to fill the chip
+    // (weights may then be (hi, lo) pairs -- policies "x2s" / "x2w": second K sweep against the lo image; of the stacked
+    // q|k|v image only the V rows may have one), the tile kernels with 64-column slots below that (single weights).
+    const bool fold_ok = ln_fold_choice() != 0 && p.x16b && x.C >= 512 && x.C <= 1536 && (x.C % 256) == 0 &&
+                         x.stride_t == x.C && (B == 1 || x.stride_b == (int64_t)N * x.C) && !sa.attn.act_split &&
+                         !sa.mlp.act_split && sa.attn.qkv.w_hi &&
+                         (!sa.fold.qkv.w_lo || sa.fold.qkv.lo_row0 == 2 * sa.attn.heads * sa.attn.dkp) &&
+                         (!sa.fold.fc1.w_lo || sa.fold.fc1.lo_row0 == 0) && flash_supported(sa.attn.dkp, sa.attn.dvp) &&
+                         sa.fold.qkv.n == sa.attn.qkv.n && sa.fold.qkv.k == x.C && sa.fold.fc1.k == x.C &&
+                         sa.fold.fc1.n == sa.mlp.fc1.n && sa.mlp.hidden == x.C && sa.mlp.dtype == sa.attn.dtype &&
+                         !kv_mask && !q_mask && !full_mask && !attention_bias && !probs_out &&
+                         (((uintptr_t)x.data) & 15) == 0;
+    const bool fold_wide = fold_ok && rows >= ln_fold_min_rows();
+    const bool fold_small = fold_ok && !fold_wide && rows >= ln_fold_small_min_rows() && !sa.fold.qkv.w_lo &&
+                            !sa.fold.fc1.w_lo && !sa.attn.o.w_lo && !sa.mlp.fc2.w_lo;
+    const bool fold = fold_wide || fold_small;
     if (fold) {
+        const int slot_w = fold_wide ? 128 : 64, nslots = x.C / slot_w;
         // x16 / part_a: the block input (from the previous block's fc2, or computed here for the first block)
         // Inside the fold the residual stream is the 16-bit pair (x16, lo): 22 mantissa bits, and 64 MB less traffic
         // per residual GEMM than fp32 + copy.  The fp32 form is read here once (first block) and written when the
         // caller needs it (last block).
         if (!(carry && carry->x == x.data && carry->x16 == p.x16.hi && carry->part == p.part_a)) {
             if (carry && !carry->f32_valid) return PIO_E_ARG;  // (the stack decides the fold for all its blocks)
-            PIO_TRY(rowstats_cast_launch(x.data, rows, p.x16.hi, p.lo_a, p.part_a, sa.attn.dtype, s));
+            PIO_TRY(rowstats_cast_launch(x.data, rows, x.C, slot_w, p.x16.hi, p.lo_a, p.part_a, sa.attn.dtype, s));
         }
         const Pair xa = {p.x16.hi, nullptr};
         LnFold f_qkv, f_out, f_fc1, f_fc2;
@@ -577,6 +618,8 @@ static int self_attention_run(const pio_self_attention_t &sa, const pio_tensor3_
         f_out.out16 = p.x16b; f_out.ld16 = x.C; f_out.out_part = p.part_b;
         f_out.out16_lo = p.lo_b; f_out.res16_hi = p.x16.hi; f_out.res16_lo = p.lo_a;
         f_out.range_flag = f_fc2.range_flag = sa.fold.range_flag;
+        f_qkv.in_slots = f_fc1.in_slots = nslots;
+        f_out.slot_w = f_fc2.slot_w = slot_w;
         f_fc1.in_part = p.part_b; f_fc1.w = &sa.fold.fc1; f_fc1.c = sa.fold.fc1_c; f_fc1.eps = sa.ln2.eps;
         f_fc2.out16 = p.x16.hi; f_fc2.ld16 = x.C; f_fc2.out_part = p.part_a;
         f_fc2.out16_lo = p.lo_a; f_fc2.res16_hi = p.x16b; f_fc2.res16_lo = p.lo_b;
@@ -757,7 +800,16 @@ size_t pio_self_attention_workspace_bytes(const pio_self_attention_t *sa, int32_
 int pio_self_attention_fwd(const pio_self_attention_t *sa, const pio_tensor3_t *x, const uint8_t *kv_mask,
                            const uint8_t *q_mask, const uint8_t *full_mask, const float *attention_bias, float *out,
                            float *probs_out, void *workspace, size_t workspace_bytes, void *stream) {
+    return pio_self_attention_fwd_opts(sa, x, kv_mask, q_mask, full_mask, attention_bias, out, probs_out, workspace,
+                                       workspace_bytes, stream, nullptr);
+}
+
+int pio_self_attention_fwd_opts(const pio_self_attention_t *sa, const pio_tensor3_t *x, const uint8_t *kv_mask,
+                                const uint8_t *q_mask, const uint8_t *full_mask, const float *attention_bias,
+                                float *out, float *probs_out, void *workspace, size_t workspace_bytes, void *stream,
+                                const pio_call_opts_t *opts) {
     if (!sa || !x || !out || !workspace) return PIO_E_ARG;
+    CallOpts scope(opts);
     SelfPlan p;
     if (p.carve(workspace, *sa, x->B, x->T) > workspace_bytes) return PIO_E_WORKSPACE;
     return self_attention_run(*sa, *x, kv_mask, q_mask, full_mask, attention_bias, out, probs_out, p,
@@ -817,7 +869,17 @@ int pio_encoder_fwd_blocks(const pio_cross_attention_t *cross, const pio_self_at
                            int32_t num_blocks, int32_t per_block, const pio_tensor3_t *inputs,
                            const pio_tensor3_t *inputs_tail, const pio_tensor3_t *latents, const uint8_t *input_mask,
                            float *out, void *workspace, size_t workspace_bytes, void *stream) {
+    return pio_encoder_fwd_opts(cross, layers, L, num_blocks, per_block, inputs, inputs_tail, latents, input_mask, out,
+                                workspace, workspace_bytes, stream, nullptr);
+}
+
+int pio_encoder_fwd_opts(const pio_cross_attention_t *cross, const pio_self_attention_t *layers, int32_t L,
+                         int32_t num_blocks, int32_t per_block, const pio_tensor3_t *inputs,
+                         const pio_tensor3_t *inputs_tail, const pio_tensor3_t *latents, const uint8_t *input_mask,
+                         float *out, void *workspace, size_t workspace_bytes, void *stream,
+                         const pio_call_opts_t *opts) {
     if (!cross || !inputs || !latents || !out || !workspace || (L > 0 && !layers)) return PIO_E_ARG;
+    CallOpts scope(opts);
     if (L < 0 || num_blocks < 0) return PIO_E_SHAPE;
     hipStream_t s = (hipStream_t)stream;
     const int B = inputs->B, M = inputs->T, N = latents->T, D = latents->C;

@@ -47,13 +47,22 @@ ProfScope::~ProfScope() {
 
 // CU budget of the persistent kernels' grids (pio_set_cu_budget): 0 = every CU of the device
 static int g_cu_budget = 0;
+// ... and the per-call value (pio_call_opts_t.cu_budget), thread-local for the duration of a *_opts call: it wins over
+// the process-wide one.  cu_budget_call(v >= 0) sets it, any call returns the previous value.
+static thread_local int tl_cu_budget = 0;
+int cu_budget_call(int v) {
+    const int prev = tl_cu_budget;
+    if (v >= 0) tl_cu_budget = v;
+    return prev;
+}
 int cu_budget() {
     static const int n_cu = [] {
         int dev = 0, n = 256;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
         return n > 0 ? n : 256;
     }();
-    return (g_cu_budget > 0 && g_cu_budget < n_cu) ? g_cu_budget : n_cu;
+    const int want = tl_cu_budget > 0 ? tl_cu_budget : g_cu_budget;
+    return (want > 0 && want < n_cu) ? want : n_cu;
 }
 }  // namespace pio
 

@@ -225,31 +225,33 @@ __global__ __launch_bounds__(256) void layernorm_cast_reg_kernel(const float *__
     }
 }
 
-// LayerNorm fold, first layer of a stack: y = cast(x) (NOT normalised; optionally y_lo = x - y) and, per row and 128-column block, the (sum,
-// sum of squares) that the fold's consumer GEMM turns into mean / rstd.  C == 1024, contiguous rows; one wave per row:
-// float4 j of lane l covers columns 256 j + 4 l, i.e. block 2 j + (l >> 5).
-template <int DT>
-__global__ __launch_bounds__(256) void rowstats_cast_kernel(const float *__restrict__ x, int64_t rows,
+// LayerNorm fold, first layer of a stack: y = cast(x) (NOT normalised; optionally y_lo = x - y) and, per row and slot of
+// SW columns (128: the wide GEMM kernel's consumer; 64: the tile kernels'), the (sum, sum of squares) that the fold's
+// consumer GEMM turns into mean / rstd.  C % 256 == 0, contiguous rows; one wave per row: float4 j of lane l covers
+// columns 256 j + 4 l, i.e. slot (256 j + 4 l) / SW.
+template <int DT, int SW>
+__global__ __launch_bounds__(256) void rowstats_cast_kernel(const float *__restrict__ x, int64_t rows, int C,
                                                             typename Op<DT>::T *__restrict__ y,
                                                             typename Op<DT>::T *__restrict__ y_lo,
                                                             float *__restrict__ part) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
-    const float *xr = x + row * 1024;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    const float *xr = x + row * C;
+    const int nslots = C / SW;
+    constexpr int LPS = SW / 4;  // lanes per slot (32 or 16)
+    for (int j = 0; j < C / 256; ++j) {
         const int i = (j * 64 + lane) * 4;
         const f32x4 v = *(const f32x4 *)(xr + i);
         float sm = (v[0] + v[1]) + (v[2] + v[3]);
         float sq = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
 #pragma unroll
-        for (int o = 16; o > 0; o >>= 1) {
+        for (int o = LPS / 2; o > 0; o >>= 1) {
             sm += __shfl_xor(sm, o, 64);
             sq += __shfl_xor(sq, o, 64);
         }
-        if ((lane & 31) == 0) {
-            float *dst = part + (row * 8 + 2 * j + (lane >> 5)) * 2;
+        if ((lane & (LPS - 1)) == 0) {
+            float *dst = part + (row * nslots + i / SW) * 2;
             dst[0] = sm;
             dst[1] = sq;
         }
@@ -259,26 +261,31 @@ __global__ __launch_bounds__(256) void rowstats_cast_kernel(const float *__restr
             o4[e] = Op<DT>::from_f32(v[e]);
             l4[e] = Op<DT>::from_f32(v[e] - Op<DT>::to_f32(o4[e]));
         }
-        *(typename Op<DT>::V4 *)(y + row * 1024 + i) = o4;
-        if (y_lo) *(typename Op<DT>::V4 *)(y_lo + row * 1024 + i) = l4;
+        *(typename Op<DT>::V4 *)(y + row * C + i) = o4;
+        if (y_lo) *(typename Op<DT>::V4 *)(y_lo + row * C + i) = l4;
     }
 }
 
-int rowstats_cast_launch(const float *x, int64_t rows, void *y16, void *y16_lo, float *part, int dtype,
+int rowstats_cast_launch(const float *x, int64_t rows, int C, int slot_w, void *y16, void *y16_lo, float *part, int dtype,
                          hipStream_t s) {
     if (!x || !y16 || !part || rows <= 0) return PIO_E_ARG;
+    if (C <= 0 || (C % 256) || (slot_w != 64 && slot_w != 128)) return PIO_E_SHAPE;
     if (((uintptr_t)x & 15) || ((uintptr_t)y16 & 7) || ((uintptr_t)part & 7)) return PIO_E_ALIGN;
     if ((uintptr_t)y16_lo & 7) return PIO_E_ALIGN;
-    ProfScope prof(PROF_LAYERNORM, 0.0, (double)rows * 1024 * (y16_lo ? 8.0 : 6.0), s);
+    ProfScope prof(PROF_LAYERNORM, 0.0, (double)rows * C * (y16_lo ? 8.0 : 6.0), s);
     const unsigned blocks = (unsigned)((rows + 3) / 4);
-    if (dtype == PIO_DT_F16)
-        hipLaunchKernelGGL((rowstats_cast_kernel<PIO_DT_F16>), dim3(blocks), dim3(256), 0, s, x, rows,
-                           (Op<PIO_DT_F16>::T *)y16, (Op<PIO_DT_F16>::T *)y16_lo, part);
-    else if (dtype == PIO_DT_BF16)
-        hipLaunchKernelGGL((rowstats_cast_kernel<PIO_DT_BF16>), dim3(blocks), dim3(256), 0, s, x, rows,
-                           (Op<PIO_DT_BF16>::T *)y16, (Op<PIO_DT_BF16>::T *)y16_lo, part);
-    else
+#define PIO_RS(DTV, SWV)                                                                                            \
+    hipLaunchKernelGGL((rowstats_cast_kernel<DTV, SWV>), dim3(blocks), dim3(256), 0, s, x, rows, C, (Op<DTV>::T *)y16, \
+                       (Op<DTV>::T *)y16_lo, part)
+    if (dtype == PIO_DT_F16) {
+        if (slot_w == 128) PIO_RS(PIO_DT_F16, 128);
+        else PIO_RS(PIO_DT_F16, 64);
+    } else if (dtype == PIO_DT_BF16) {
+        if (slot_w == 128) PIO_RS(PIO_DT_BF16, 128);
+        else PIO_RS(PIO_DT_BF16, 64);
+    } else
         return PIO_E_ARG;
+#undef PIO_RS
     return launch_status();
 }
 

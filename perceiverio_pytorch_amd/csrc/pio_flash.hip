@@ -39,17 +39,30 @@ struct FlashParams {
 
 static __device__ __attribute__((aligned(16))) uint32_t g_zero_chunk_f[4] = {0, 0, 0, 0};
 
-// VROW = true (DV = 128 only): V is consumed ROW-major ([keys][H*dv], the layout a plain projection GEMM writes, so
-// Q | K | V come out of ONE fused GEMM) through transposed LDS reads; VROW = false: V^T [dv][keys] as before.
+// VROW = true: V is consumed ROW-major ([keys][H*dv], the layout a plain projection GEMM writes, so Q | K | V come out
+// of ONE fused GEMM) through transposed LDS reads; VROW = false: V^T [dv][keys] as before.
+// Row-major tile in LDS: key row r at byte r * DV * 2, its 16-byte chunk c at position c ^ vrow_swz<DV>(r).  One
+// ds_read_b64_tr_b16 touches, per half wave, 4 consecutive keys x 4 consecutive chunks (4d .. 4d+3): conflict-free when
+// those 16 units fall into 16 different 16-byte bank slots, slot = (r * DV / 8 + position) mod 16 --
+//   DV = 128 (16 chunks per row): slot = position: f(r) = ((r & 3) << 2) | ((r >> 2) & 3) (also conflict-free row reads)
+//   DV = 64  ( 8 chunks per row): slot = 8 (r & 1) + position: f(r) = ((r >> 1) & 1) << 2
+//   DV = 32, 160 (4, 20 chunks):  slot = 4 (r & 3) + position mod 16: no swizzle needed
 // NW = waves per workgroup: 4 (128 query rows, two workgroups per CU) or 8 (256 query rows, one workgroup per CU:
 // every staged K / V tile then serves twice the queries, i.e. half the L2 -> LDS traffic per flop).
+template <int DV>
+__device__ __forceinline__ int vrow_swz(int r) {
+    if constexpr (DV == 128) return ((r & 3) << 2) | ((r >> 2) & 3);
+    else if constexpr (DV == 64) return ((r >> 1) & 1) << 2;
+    else return 0;
+}
+
 template <int DT, int DK, int DV, bool VROW, int NW>
 __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void flash_attn_kernel(const FlashParams p) {
     typedef typename Op<DT>::T T;
     typedef typename Op<DT>::V8 V8;
     typedef typename Op<DT>::V4 V4;
     typedef short tr4 __attribute__((__vector_size__(4 * sizeof(short))));
-    static_assert(!VROW || DV == 128, "row-major V path is written for 256-byte V rows");
+    static_assert(!VROW || DV == 128 || DV == 64 || DV == 32 || DV == 160, "row-major V: swizzles exist for these widths");
     constexpr int KT = 64;                       // keys per tile
     constexpr int K_TILE = KT * DK * 2;          // bytes
     constexpr int V_TILE = DV * KT * 2;          // bytes
@@ -101,11 +114,13 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void flash_attn_kernel(co
                                              (__attribute__((address_space(3))) void *)(kb + pc * 1024), 16, 0, 0);
         }
         if constexpr (VROW) {
-            // row-major V tile [64 keys][DV = 128]: 256-byte rows (16 chunks), a 1-KiB piece = 4 key rows
+            // row-major V tile [64 keys][DV]: DV / 8 chunks per row, a 1-KiB piece = 64 consecutive chunks
+            constexpr int VCPR = DV / 8;
             for (int pc = wave; pc < V_PIECES; pc += NW) {
-                const int row = pc * 4 + (lane >> 4);
-                const int slot = lane & 15;
-                const int c = slot ^ (((row & 3) << 2) | ((row >> 2) & 3));
+                const int idx = pc * 64 + lane;
+                const int row = idx / VCPR;
+                const int slot = idx - row * VCPR;
+                const int c = slot ^ vrow_swz<DV>(row);
                 int key = k0 + row;
                 key = key < p.Tk ? key : p.Tk - 1;
                 const T *src = Vg + (int64_t)key * p.ldvt + c * 8;
@@ -230,17 +245,17 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void flash_attn_kernel(co
                 for (int s = 0; s < 2; ++s) {
                     V4 lo, hi;
                     if constexpr (VROW) {
-                        // V tile is ROW-major [64 keys][DV] (256-byte rows); the fragment is read TRANSPOSED by
+                        // V tile is ROW-major [64 keys][DV]; the fragment is read TRANSPOSED by
                         // ds_read_b64_tr_b16: per 16-lane group a 4-key x 16-column block, lane 4q+p supplies the
                         // address of key q / columns 4p..4p+3 and receives its own column of the 4 keys.
-                        // chunk swizzle f(row) = ((row&3)<<2) | ((row>>2)&3) (conflict-free for row and tr reads)
+                        // chunk swizzle vrow_swz<DV>(row): conflict-free transposed reads (see the top of the kernel)
                         const int q4 = (lane & 15) >> 2, p4 = lane & 3, g1 = (lane >> 4) & 1;
                         const int chunk = d * 4 + 2 * g1 + (p4 >> 1);
 #pragma unroll
                         for (int jj = 0; jj < 2; ++jj) {
                             const int key = 32 * t + 16 * s + 8 * jj + 4 * hh + q4;
-                            const int f = (q4 << 2) | ((hh + 2 * jj) & 3);
-                            const char *a = vb + key * 256 + ((chunk ^ f) << 4) + 8 * (p4 & 1);
+                            const int f = vrow_swz<DV>(key);
+                            const char *a = vb + key * (DV * 2) + ((chunk ^ f) << 4) + 8 * (p4 & 1);
                             const tr4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                                 (__attribute__((address_space(3))) tr4 *)a);
                             if (jj == 0) lo = __builtin_bit_cast(V4, r);
@@ -333,12 +348,11 @@ int flash_variant_override(int which) {
 extern "C" int pio_debug_flash_variant(int which) { return flash_variant_override(which); }
 #endif
 
-// v_rowmajor: VT points at V [B][Tk][.. h*dvp ..] (row stride ldvt) instead of V^T [B][H*dvp][Tk]; dvp == 128 only.
+// v_rowmajor: VT points at V [B][Tk][.. h*dvp ..] (row stride ldvt) instead of V^T [B][H*dvp][Tk].
 int flash_attention_launch(int dtype, int dkp, int dvp, int dk_logical, const void *Q, const void *K, const void *VT,
                            void *O, int B, int H, int Tq, int Tk, int64_t ldq, int64_t ldk, int64_t ldvt, int64_t ldo,
                            int64_t sQb, int64_t sKb, int64_t sVb, int64_t sOb, bool v_rowmajor, hipStream_t s) {
     if (!flash_supported(dkp, dvp)) return PIO_E_SHAPE;
-    if (v_rowmajor && !(dkp == 128 && dvp == 128)) return PIO_E_SHAPE;
     if (!Q || !K || !VT || !O) return PIO_E_ARG;
     if (B <= 0 || H <= 0 || Tq <= 0 || Tk <= 0 || (int64_t)B * H * ((Tq + 127) / 128) > 0x7fffffffLL) return PIO_E_SHAPE;
     if ((ldq % 8) || (ldk % 8) || (ldvt % 8) || (ldo % 4) || (sQb % 8) || (sKb % 8) || (sVb % 8) || (sOb % 4))
@@ -386,12 +400,24 @@ int flash_attention_launch(int dtype, int dkp, int dvp, int dk_logical, const vo
         else hipLaunchKernelGGL((flash_attn_stag_kernel<PIO_DT_BF16>), grid, block, 0, s, p);
     } else
 #endif
-    if (v_rowmajor && wide) {
-        if (dtype == PIO_DT_F16) hipLaunchKernelGGL((flash_attn_kernel<PIO_DT_F16, 128, 128, true, 8>), grid, block, 0, s, p);
-        else hipLaunchKernelGGL((flash_attn_kernel<PIO_DT_BF16, 128, 128, true, 8>), grid, block, 0, s, p);
-    } else if (v_rowmajor) {
-        if (dtype == PIO_DT_F16) hipLaunchKernelGGL((flash_attn_kernel<PIO_DT_F16, 128, 128, true, 4>), grid, block, 0, s, p);
-        else hipLaunchKernelGGL((flash_attn_kernel<PIO_DT_BF16, 128, 128, true, 4>), grid, block, 0, s, p);
+    if (v_rowmajor) {
+#define PIO_FLASH_ROW(DKV, DVV)                                                                                        \
+    do {                                                                                                               \
+        if (wide) {                                                                                                    \
+            if (dtype == PIO_DT_F16)                                                                                   \
+                hipLaunchKernelGGL((flash_attn_kernel<PIO_DT_F16, DKV, DVV, true, 8>), grid, block, 0, s, p);          \
+            else hipLaunchKernelGGL((flash_attn_kernel<PIO_DT_BF16, DKV, DVV, true, 8>), grid, block, 0, s, p);        \
+        } else {                                                                                                       \
+            if (dtype == PIO_DT_F16)                                                                                   \
+                hipLaunchKernelGGL((flash_attn_kernel<PIO_DT_F16, DKV, DVV, true, 4>), grid, block, 0, s, p);          \
+            else hipLaunchKernelGGL((flash_attn_kernel<PIO_DT_BF16, DKV, DVV, true, 4>), grid, block, 0, s, p);        \
+        }                                                                                                              \
+    } while (0)
+        if (dkp == 128 && dvp == 128) PIO_FLASH_ROW(128, 128);
+        else if (dkp == 64 && dvp == 64) PIO_FLASH_ROW(64, 64);
+        else if (dkp == 32 && dvp == 32) PIO_FLASH_ROW(32, 32);
+        else PIO_FLASH_ROW(32, 160);
+#undef PIO_FLASH_ROW
     } else if (dkp == 128 && dvp == 128) PIO_FLASH_DT(128, 128);
     else if (dkp == 64 && dvp == 64) PIO_FLASH_DT(64, 64);
     else if (dkp == 32 && dvp == 32) PIO_FLASH_DT(32, 32);

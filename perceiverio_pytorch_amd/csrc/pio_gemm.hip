@@ -41,7 +41,8 @@ __global__ __launch_bounds__(256) void gemm_nt_128(const GemmParams p) {
     constexpr int A_PPW = TM / 32, B_PPW = TN / 32;                  // 1-KiB pieces (8 rows) per wave
     constexpr int MI = TM / 32, NI = TN / 32;                        // 16 x 16 units per wave (waves as 2 x 2)
     constexpr int EPI_BYTES = TM * TN * 4;
-    constexpr int SMEM = NS * (A_BYTES + B_BYTES) > EPI_BYTES ? NS * (A_BYTES + B_BYTES) : EPI_BYTES;
+    // (+ TM x (rstd, -mean rstd) behind the epilogue image: the LayerNorm fold's consumer)
+    constexpr int SMEM = (NS * (A_BYTES + B_BYTES) > EPI_BYTES ? NS * (A_BYTES + B_BYTES) : EPI_BYTES) + TM * 8;
     static_assert(NS == 2 || (NS - 2) * (A_PPW + B_PPW) <= 63, "the counted wait must fit vmcnt");
     __shared__ __attribute__((aligned(16))) char smem[SMEM];        // A stages, B stages (then the epilogue image)
 
@@ -184,6 +185,26 @@ __global__ __launch_bounds__(256) void gemm_nt_128(const GemmParams p) {
             *(f32x4 *)(cs + ml * TN + ((c ^ (ml & (CPR - 1))) << 2)) = acc[mi][ni];
         }
     }
+    // LayerNorm fold on the small tiles (stacks too short for the 256 x 256 kernel: the flow / multimodal latents, small
+    // batches).  Consumer: row m's (mean, rstd) from the ln_slots partial (sum, sum of squares) pairs its producer left,
+    // once per tile row, parked behind the image.  Producer (below): residual pair in, result pair out, 64-column sums.
+    float *const stat = (float *)(smem + SMEM - TM * 8);
+    if (p.ln_part && tid < TM) {
+        int m = tile_m * TM + tid;
+        m = m < p.M ? m : p.M - 1;
+        const float *pr = p.ln_part + (int64_t)m * p.ln_slots * 2;
+        float sm = 0.f, sq = 0.f;
+        for (int i = 0; i < p.ln_slots; ++i) {
+            sm += pr[2 * i];
+            sq += pr[2 * i + 1];
+        }
+        const float mean = sm * p.ln_inv_k;
+        float var = sq * p.ln_inv_k - mean * mean;
+        var = var > 0.f ? var : 0.f;
+        const float rstd = 1.0f / sqrtf(var + p.ln_eps);
+        stat[2 * tid] = rstd;
+        stat[2 * tid + 1] = -mean * rstd;
+    }
     __syncthreads();
     const int64_t coffz = zb * p.sCb + zh * p.sCh;
     const int c = tid & (CPR - 1);
@@ -201,12 +222,58 @@ __global__ __launch_bounds__(256) void gemm_nt_128(const GemmParams p) {
                     if (n0 + r < p.N) bias_n[r] = p.bias[n0 + r];
             }
         }
+        f32x4 lnc = {0.f, 0.f, 0.f, 0.f};
+        if (p.ln_part) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (n0 + r < p.N) lnc[r] = p.ln_c[n0 + r];
+        }
 #pragma unroll 4
         for (int it = 0; it < TM / RPI; ++it) {
             const int ml = it * RPI + tid / CPR;
             const int m = tile_m * TM + ml;
             if (m >= p.M) break;  // rows are visited in increasing order
             f32x4 v = *(const f32x4 *)(cs + ml * TN + ((c ^ (ml & (CPR - 1))) << 2));
+            if (p.row_part) {
+                // ---- fold producer (launcher: N % 64 == 0, n_store == N, 16-bit rows 8-byte aligned): x = acc + bias +
+                // residual pair, leaves as the pair (X16, X16_lo) [+ fp32 C] with the row's (sum, sum of squares) over
+                // this thread group's 64 columns; the 16 lanes of a group sit in one wave and share the row
+                typedef typename Op<DT>::V4 V4;
+                const V4 hh = *(const V4 *)((const T *)p.R16_hi + (int64_t)m * p.ld16 + n0);
+                const V4 ll = *(const V4 *)((const T *)p.R16_lo + (int64_t)m * p.ld16 + n0);
+                V4 h, l;
+                float rsum = 0.f, rsq = 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float x = v[r] * p.alpha + bias_n[r] + (Op<DT>::to_f32(hh[r]) + Op<DT>::to_f32(ll[r]));
+                    v[r] = x;
+                    h[r] = Op<DT>::from_f32(x);
+                    l[r] = Op<DT>::from_f32(x - Op<DT>::to_f32(h[r]));
+                    rsum += x;
+                    rsq += x * x;
+                }
+                *(V4 *)((T *)p.X16 + (int64_t)m * p.ld16 + n0) = h;
+                *(V4 *)((T *)p.X16_lo + (int64_t)m * p.ld16 + n0) = l;
+                if (p.C) *(f32x4 *)((float *)p.C + (int64_t)m * p.ldc + n0) = v;
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) {
+                    rsum += __shfl_xor(rsum, o, 64);
+                    rsq += __shfl_xor(rsq, o, 64);
+                }
+                if ((tid & 15) == 0) {
+                    float *dst = p.row_part + ((int64_t)m * (p.N >> 6) + (n0 >> 6)) * 2;
+                    dst[0] = rsum;
+                    dst[1] = rsq;
+                    if (p.range_flag && !(rsq <= 3.0e38f)) *p.range_flag = 1;
+                }
+                continue;
+            }
+            if (p.ln_part) {
+                // ---- fold consumer: LayerNorm(x) W^T + b = rstd (x W'^T) - rstd mean c + b'   (alpha == 1: launcher)
+                const float rs = stat[2 * ml], nm = stat[2 * ml + 1];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = v[r] * rs + nm * lnc[r];
+            }
             const float bias_m = (p.bias_mode == 2) ? p.bias[m] : 0.f;
             const float *rrow = nullptr;
             if (p.R) {
@@ -344,6 +411,10 @@ int gemm_nt_launch(const pio_gemm_t &g, hipStream_t s) {
     p.X16_lo = g.X16_lo; p.R16_hi = g.R16_hi; p.R16_lo = g.R16_lo;
     p.range_flag = g.row_part ? g.range_flag : nullptr;
     p.lo_n0 = g.B_lo ? g.b_lo_n0 : 0;
+    p.k_rev = 0;
+    p.ln_slots = g.ln_part ? (g.ln_slots > 0 ? g.ln_slots : g.K / 128) : 0;
+    p.ln_inv_k = 1.0f / (float)g.K;
+    p.slot_w = g.row_part ? (g.row_slot_w > 0 ? g.row_slot_w : 128) : 0;
     {
         // A/B switch: env PIO_WIDE_STAGED_EPI=0 keeps the direct (16 rows x 64 bytes per instruction) epilogue
         static const int staged = [] {
@@ -393,6 +464,7 @@ int gemm_nt_launch(const pio_gemm_t &g, hipStream_t s) {
     {
         const int forced = gemm_kernel_choice();
         const int tn256 = (p.n_store + 255) / 256, tm256 = (g.M + 255) / 256;
+        bool fold_small = false;
         bool big = g.batch == 1 && g.M >= 1024 && p.n_store >= 256 && (double)tn256 * 256.0 <= 1.25 * p.n_store &&
                    (int64_t)tm256 * tn256 >= 128;
         if (forced == 128) big = false;
@@ -417,7 +489,23 @@ int gemm_nt_launch(const pio_gemm_t &g, hipStream_t s) {
             if (forced == 2) wide = true;
             if (forced == 1 || forced == 128 || forced == 256) wide = false;
             const bool fold = p.X16 || p.row_part || p.ln_part || p.ln_c || p.X16_lo || p.R16_hi || p.R16_lo;
-            if (fold) {
+            // The fold on the small tiles (a stack too short for 256 x 256 tiles): chosen by the caller through the slot
+            // form -- a producer asked for 64-column slots, a consumer given anything but K / 128 slots (or a shape the
+            // wide kernel does not take).
+            fold_small = fold && (p.row_part ? p.slot_w == 64
+                                             : (p.ln_slots != g.K / 128 || g.M < 2048 || !gemm_wide_ok(p, g.batch)));
+            if (fold_small) {
+                if (g.batch != 1 || p.npass != 1 || p.lo_n0 || g.bias_mode > 1) return PIO_E_SHAPE;
+                if (p.row_part) {  // producer
+                    if (!p.X16 || !p.X16_lo || !p.R16_hi || !p.R16_lo || !g.out_f32 || p.R || (g.N & 63) || p.n_store != g.N ||
+                        (p.ld16 & 3) || ((uintptr_t)p.X16 & 7) || ((uintptr_t)p.X16_lo & 7) || ((uintptr_t)p.R16_hi & 7) ||
+                        ((uintptr_t)p.R16_lo & 7) || p.ln_part || g.act != 0 || (g.C && ((g.ldc & 3) || ((uintptr_t)g.C & 15))))
+                        return PIO_E_SHAPE;
+                } else {           // consumer
+                    if (!p.ln_part || !p.ln_c || g.out_f32 || g.alpha != 1.0f || p.ln_slots <= 0) return PIO_E_SHAPE;
+                }
+                wide = false;
+            } else if (fold) {
 #ifdef PIO_EXPERIMENTS
                 // (experiments build) the producer on two half-height workgroups per CU: override 3 / env PIO_GEMM_DUO=1
                 static const bool duo_env = [] {
@@ -442,12 +530,13 @@ int gemm_nt_launch(const pio_gemm_t &g, hipStream_t s) {
             }
         }
         if (p.lo_n0) return PIO_E_SHAPE;  // (a partial B_lo is a gemm_nt_wide feature)
+        if (fold_small) big = false;
         // Persistent 256x128 streaming kernel (epilogue of tile j hidden behind the MFMAs of tile j+1): deep-K flat
         // problems with about two or more tiles per CU (with fewer there is nothing to hide an epilogue behind and
         // the 256x256 tile's lower operand traffic wins).  Override 1 forces it wherever it is legal.
         {
             const int tn128 = (p.n_store + 127) / 128;
-            bool stream = g.batch == 1 && g.M >= 1024 && p.n_store >= 128 &&
+            bool stream = !fold_small && g.batch == 1 && g.M >= 1024 && p.n_store >= 128 &&
                           (double)tn128 * 128.0 <= 1.25 * p.n_store && (int64_t)tm256 * tn128 >= 448;
             if (forced == 1) stream = true;
             if (forced == 128 || forced == 256) stream = false;

@@ -37,6 +37,11 @@ struct GemmParams {
     void *X16_lo;
     const void *R16_hi, *R16_lo;
     int *range_flag;  // producer: set to 1 when a row statistic is not finite (the folded stack's fp16 range guard)
+    // consumer: ln_part holds ln_slots (sum, sum of squares) pairs per row (K / 128 from the wide kernel's producer, K / 64
+    // from the small-tile kernels'), ln_inv_k = 1 / K; producer: slot_w = columns per slot (128 wide kernel, 64 small tiles)
+    int ln_slots;
+    float ln_inv_k;
+    int slot_w;
 };
 
 

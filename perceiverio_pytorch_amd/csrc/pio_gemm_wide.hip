@@ -384,6 +384,7 @@ __global__ __launch_bounds__(256) void gemm_nt_wide(const GemmParams p, int tile
                 if (extra == 0) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
                 else if (extra == 1) asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
                 else if (extra == 10) asm volatile("s_waitcnt vmcnt(26)" ::: "memory");
+                else if (extra == 18) asm volatile("s_waitcnt vmcnt(34)" ::: "memory");
                 else if (extra == 33) asm volatile("s_waitcnt vmcnt(49)" ::: "memory");
                 else if (extra == 42) asm volatile("s_waitcnt vmcnt(58)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(63)" ::: "memory");  // (the counter's ceiling: stricter than needed)
@@ -432,8 +433,10 @@ __global__ __launch_bounds__(256) void gemm_nt_wide(const GemmParams p, int tile
         // of the bias / c rows at the head of the tile's first phase
         // (LNF == 2: + the 8 loads of the row statistics, issued here at the head of the tile and consumed in its
         //  epilogue -- they ride through the main loop in 32 of the ~100 free VGPRs instead of exposing their latency)
-        constexpr int NDMA0 = LNF == 2 ? 10 : 1;
+        // (K > 1024: slots 8 .. 11 ride in part2 -- one more 8-byte load per row block)
+        constexpr int NDMA0 = LNF == 2 ? (MF == 1 ? 10 : 18) : 1;
         f32x4 part[8];
+        pio_f32x2 part2[8];
         if constexpr (LNF == 2 && MF == 1) {
             // (row 32 mi + (lane & 31): the (sum, sum of squares) of column blocks 4 (lane >> 5) .. + 3 -- two loads)
 #pragma unroll
@@ -444,11 +447,16 @@ __global__ __launch_bounds__(256) void gemm_nt_wide(const GemmParams p, int tile
                 part[2 * mi + 1] = *(const f32x4 *)(src + 4);
             }
         } else if constexpr (LNF == 2) {
+            // lane group fq takes slots 2 fq, 2 fq + 1 and (K > 1024) 8 + fq of its rows; slots the row does not have read
+            // a zero block (ln_slots is even: the wide producer writes K / 128 of them)
+            const int ns = p.ln_slots;
 #pragma unroll
             for (int mi = 0; mi < 8; ++mi) {
                 int m = o_m + mi * 16;
                 m = m < p.M ? m : p.M - 1;
-                part[mi] = *(const f32x4 *)(p.ln_part + ((int64_t)m * 8 + 2 * fq) * 2);
+                const float *pr = p.ln_part + (int64_t)m * ns * 2;
+                part[mi] = *(const f32x4 *)(2 * fq < ns ? pr + 4 * fq : (const float *)g_zero_w);
+                part2[mi] = *(const pio_f32x2 *)(8 + fq < ns ? pr + 16 + 2 * fq : (const float *)g_zero_w);
             }
         }
         constexpr int NSTORE = OUT == 2 ? 64 : 32;
@@ -824,19 +832,19 @@ __global__ __launch_bounds__(256) void gemm_nt_wide(const GemmParams p, int tile
             }
         } else {
         T *const cbase = (T *)p.C;
-        // (LNF == 2) mean / rstd of this lane's eight rows from the producer's partial sums: lane group fq adds blocks
-        // 2 fq and 2 fq + 1 (K == 1024: eight 128-column blocks), two butterfly steps add the four groups
+        // (LNF == 2) mean / rstd of this lane's eight rows from the producer's partial sums: lane group fq adds slots
+        // 2 fq, 2 fq + 1 and 8 + fq (K / 128 slots of 128 columns, K <= 1536), two butterfly steps add the four groups
         float rs[8], nmr[8];
         if constexpr (LNF == 2) {
 #pragma unroll
             for (int mi = 0; mi < 8; ++mi) {
-                float sm = part[mi][0] + part[mi][2], sq = part[mi][1] + part[mi][3];
+                float sm = part[mi][0] + part[mi][2] + part2[mi][0], sq = part[mi][1] + part[mi][3] + part2[mi][1];
                 sm += __shfl_xor(sm, 16);
                 sq += __shfl_xor(sq, 16);
                 sm += __shfl_xor(sm, 32);
                 sq += __shfl_xor(sq, 32);
-                const float mean = sm * (1.0f / 1024.0f);
-                float var = sq * (1.0f / 1024.0f) - mean * mean;
+                const float mean = sm * p.ln_inv_k;
+                float var = sq * p.ln_inv_k - mean * mean;
                 var = var > 0.f ? var : 0.f;
                 rs[mi] = 1.0f / sqrtf(var + p.ln_eps);
                 nmr[mi] = -mean * rs[mi];
@@ -975,7 +983,7 @@ bool gemm_wide_ok(const GemmParams &p, int batch) {
     if (p.R && (!p.out_f32 || !p.r_vec || p.r_rows != 0 || (p.ldr & 3))) return false;
     if (p.X16 || p.row_part || p.X16_lo || p.R16_hi || p.R16_lo) {  // LayerNorm-fold producer
         const bool pair_r = p.R16_hi || p.R16_lo;
-        if (!p.X16 || !p.row_part || !p.out_f32 || (p.N & 127) || (p.ld16 & 7) || ((uintptr_t)p.X16 & 15) ||
+        if (!p.X16 || !p.row_part || !p.out_f32 || (p.N & 127) || p.slot_w != 128 || (p.ld16 & 7) || ((uintptr_t)p.X16 & 15) ||
             ((uintptr_t)p.row_part & 7) || p.ln_part || p.ln_c)
             return false;
         if (pair_r ? (!p.R16_hi || !p.R16_lo || p.R || ((uintptr_t)p.R16_hi & 15) || ((uintptr_t)p.R16_lo & 15)) : !p.R)
@@ -983,8 +991,8 @@ bool gemm_wide_ok(const GemmParams &p, int batch) {
         if (((uintptr_t)p.X16_lo & 15) || (!p.C && !p.X16_lo)) return false;
     }
     if (p.ln_part || p.ln_c) {  // LayerNorm-fold consumer
-        if (!p.ln_part || !p.ln_c || p.out_f32 || p.K != 1024 || p.alpha != 1.0f || ((uintptr_t)p.ln_c & 15) ||
-            ((uintptr_t)p.ln_part & 15))
+        if (!p.ln_part || !p.ln_c || p.out_f32 || (p.K & 127) || p.K > 1536 || p.ln_slots != p.K / 128 ||
+            (p.ln_slots & 1) || p.alpha != 1.0f || ((uintptr_t)p.ln_c & 15) || ((uintptr_t)p.ln_part & 15))
             return false;
     }
     if (p.bias_mode > 1 || (p.bias_mode == 1 && !p.bias_vec)) return false;
@@ -1014,7 +1022,7 @@ void gemm_wide_launch(const GemmParams &p, int dtype, hipStream_t s) {
     }();
     const bool whole = (p.M % W_BM) == 0 && (p.N % W_BN) == 0 && p.n_store == p.N;
     const bool mf_any = mf32_on || p.mf32;
-    const bool mf_cons = mf_any && whole && p.ln_part && !p.out_f32;
+    const bool mf_cons = mf_any && whole && p.ln_part && !p.out_f32 && p.K == 1024;
     const bool mf_prod = mf_any && whole && p.row_part && p.R16_hi && !p.C && p.X16_lo && p.staged_epi &&
                          (int64_t)tiles_m * tiles_n <= G;
 #define PIO_WKM(DTV, ACT, OUT, R, LNF) \

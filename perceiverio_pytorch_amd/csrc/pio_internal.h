@@ -94,6 +94,7 @@ struct ProfScope {
 // CUs a persistent kernel may size its grid for: the device's CU count, or the budget set with pio_set_cu_budget
 // (launches on a CU-masked stream that owns only part of the chip)
 int cu_budget();
+int cu_budget_call(int v);  // per-call (thread-local) budget: v >= 0 sets it (0 = none); returns the previous value
 
 // ---- internal launchers (defined in the .hip files) ---------------------------------------------
 int gemm_nt_launch(const pio_gemm_t &g, hipStream_t s);
@@ -103,9 +104,10 @@ int layernorm_cast_launch(const pio_tensor3_t &x, const pio_layernorm_t *ln, voi
 // LayerNorm over the concatenation [x1 | x2] of two sources (x2 may be one batch-invariant table, B == 1)
 int layernorm_cast_cat_launch(const pio_tensor3_t &x1, const pio_tensor3_t &x2, const pio_layernorm_t &ln, void *y,
                               void *y_lo, int c_pad, int dtype, hipStream_t s);
-// LayerNorm fold: 16-bit cast of contiguous 1024-channel rows + their per-128-column (sum, sum of squares), the form
-// the fold's consumer GEMM reads (first layer of a stack: later layers get both from the producing GEMM)
-int rowstats_cast_launch(const float *x, int64_t rows, void *y16, void *y16_lo, float *part, int dtype,
+// LayerNorm fold: 16-bit cast of contiguous C-channel rows (C % 256 == 0) + their (sum, sum of squares) per slot of slot_w
+// (64 / 128) columns, the form the fold's consumer GEMM reads (first layer of a stack: later layers get both from the
+// producing GEMM)
+int rowstats_cast_launch(const float *x, int64_t rows, int C, int slot_w, void *y16, void *y16_lo, float *part, int dtype,
                          hipStream_t s);
 int ln_fold_enable(int on);   // returns the previous setting
 bool ln_fold_enabled();

@@ -47,11 +47,11 @@ def _gather_buffer(shape, dtype, device) -> torch.Tensor:
 
 
 def all_gather_rows(local: torch.Tensor, total_rows: Optional[int] = None, group=None,
-                    reuse_buffer: bool = True) -> torch.Tensor:
+                    reuse_buffer: bool = False) -> torch.Tensor:
     """Concatenate every rank's [b_r, ...] block along dim 0 in rank order.  Equal shards are ONE
-    all_gather_into_tensor into a preallocated [b * W, ...] buffer (reuse_buffer: the same tensor is returned by the
-    next call of this shape); ragged shards (total_rows given, not divisible) are padded to the largest shard and
-    trimmed."""
+    all_gather_into_tensor into a fresh [b * W, ...] tensor -- or, with reuse_buffer=True (a step loop that consumes
+    the result before its next call: bench.py), into ONE preallocated buffer per shape that the next call of the same
+    shape OVERWRITES; ragged shards (total_rows given, not divisible) are padded to the largest shard and trimmed."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return local
     world = dist.get_world_size(group)

@@ -117,10 +117,12 @@ class PerceiverEncoder(nn.Module):
         nsplit = R.batch_streams()
         if nsplit <= 1 or B < 2 * nsplit or B % nsplit or inputs_tail is not None or per_block:
             ws = R.workspace(dev, lib.pio_encoder_workspace_bytes(cross, layers, Lyr, B, M, N))
+            # (the un-folded repeat of the range guard is a PER-CALL option: no process state changes around the call)
+            opts = L.CallOpts(1 if self._range_fallback else 0, 0)
             with R.on_device(dev):
-                L.check(lib.pio_encoder_fwd_blocks(cross, layers, Lyr, self._num_blocks, int(per_block), R.tensor3(x),
-                                                   tail3, R.tensor3(z0), im_ptr, out.data_ptr(), ws.data_ptr(),
-                                                   ws.numel(), R.stream_ptr(dev)), "pio_encoder_fwd")
+                L.check(lib.pio_encoder_fwd_opts(cross, layers, Lyr, self._num_blocks, int(per_block), R.tensor3(x),
+                                                 tail3, R.tensor3(z0), im_ptr, out.data_ptr(), ws.data_ptr(),
+                                                 ws.numel(), R.stream_ptr(dev), opts), "pio_encoder_fwd")
             return self._finish(out, flag, inputs, inputs_tail, latents, input_mask)
         # Samples are independent: run `nsplit` batch slices as independent kernel chains on side streams so that
         # one chain's fill / drain / HBM-bound kernels overlap the other's MFMA-bound ones (each slice still fills
@@ -129,24 +131,21 @@ class PerceiverEncoder(nn.Module):
         bs = B // nsplit
         # (PIO_CU_BUDGET_ONLY=1, experiment: plain streams, but persistent grids sized for a 1/nsplit share of the chip)
         masked = (R.cu_split() or os.environ.get("PIO_CU_BUDGET_ONLY") == "1") and 32 % nsplit == 0
-        prev_budget = lib.pio_set_cu_budget(R.cu_share(nsplit)) if masked else None
-        try:
-            sides = R.side_streams(dev, nsplit)
-            for side in sides:                   # every slice starts behind the work already queued on `cur` ...
-                side.wait_stream(cur)
-            for i, side in enumerate(sides):
-                with R.on_device(dev), torch.cuda.stream(side):
-                    xs, zs = x[i * bs:(i + 1) * bs], z0[i * bs:(i + 1) * bs]
-                    ws = R.workspace(dev, lib.pio_encoder_workspace_bytes(cross, layers, Lyr, bs, M, N))
-                    mp = im_ptr + i * bs * M if im_ptr is not None else None
-                    L.check(lib.pio_encoder_fwd(cross, layers, Lyr, self._num_blocks, R.tensor3(xs), R.tensor3(zs),
-                                                mp, out[i * bs:(i + 1) * bs].data_ptr(), ws.data_ptr(), ws.numel(),
-                                                side.cuda_stream), "pio_encoder_fwd")
-            for side in sides:                   # ... and `cur` continues behind ALL of them (a wait queued between
-                cur.wait_stream(side)            # two slices would chain them one after the other)
-        finally:
-            if masked:
-                lib.pio_set_cu_budget(prev_budget)
+        # (the CU share of a masked stream travels with the call: pio_call_opts_t.cu_budget, not the process-wide setting)
+        opts = L.CallOpts(1 if self._range_fallback else 0, R.cu_share(nsplit) if masked else 0)
+        sides = R.side_streams(dev, nsplit)
+        for side in sides:                   # every slice starts behind the work already queued on `cur` ...
+            side.wait_stream(cur)
+        for i, side in enumerate(sides):
+            with R.on_device(dev), torch.cuda.stream(side):
+                xs, zs = x[i * bs:(i + 1) * bs], z0[i * bs:(i + 1) * bs]
+                ws = R.workspace(dev, lib.pio_encoder_workspace_bytes(cross, layers, Lyr, bs, M, N))
+                mp = im_ptr + i * bs * M if im_ptr is not None else None
+                L.check(lib.pio_encoder_fwd_opts(cross, layers, Lyr, self._num_blocks, 0, R.tensor3(xs), None,
+                                                 R.tensor3(zs), mp, out[i * bs:(i + 1) * bs].data_ptr(), ws.data_ptr(),
+                                                 ws.numel(), side.cuda_stream, opts), "pio_encoder_fwd")
+        for side in sides:                   # ... and `cur` continues behind ALL of them (a wait queued between
+            cur.wait_stream(side)            # two slices would chain them one after the other)
         for t in (x, z0, out):
             for side in R.side_streams(dev, nsplit):
                 t.record_stream(side)
@@ -174,15 +173,13 @@ class PerceiverEncoder(nn.Module):
         return R.forward_only(out, inputs, latents, *self.parameters())
 
     def forward_unfolded(self, inputs, latents, *, input_mask=None):
-        """The same call with the LayerNorm fold off (fp32 residual stream): the range guard's fallback."""
-        lib = L.lib()
-        prev = lib.pio_ln_fold_enable(0)
+        """The same call with the LayerNorm fold off (fp32 residual stream): the range guard's fallback.  The switch is a
+        per-call option of the library (pio_call_opts_t.ln_fold = 1), not a process-wide one."""
         self._range_fallback = True
         try:
             return self.forward(inputs, latents, input_mask=input_mask)
         finally:
             self._range_fallback = False
-            lib.pio_ln_fold_enable(prev)
 
 
 class PerceiverDecoder(nn.Module):
@@ -445,14 +442,11 @@ class PerceiverIO(nn.Module):
         with R.defer_range_checks() as guard:
             outputs = self._forward(inputs, **kw)
         if guard.pending and any(int(f.item()) != 0 for f in guard.pending):
-            lib = L.lib()
-            prev = lib.pio_ln_fold_enable(0)
-            self._encoder._range_fallback = True
+            self._encoder._range_fallback = True       # (-> pio_call_opts_t.ln_fold = 1 on the encoder's call)
             try:
                 outputs = self._forward(inputs, **kw)
             finally:
                 self._encoder._range_fallback = False
-                lib.pio_ln_fold_enable(prev)
         return outputs
 
     def _forward(self, inputs, *, subsampled_output_points=None, pos=None, input_mask=None, query_mask=None,

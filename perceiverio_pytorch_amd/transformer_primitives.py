@@ -58,6 +58,11 @@ def make_cross_attention_mask(query_mask: torch.Tensor, kv_mask: torch.Tensor) -
     return mask
 
 
+# per-head (qk, v) widths, padded to 8, that the fused self-attention kernel covers with V read row-major (pio_flash.hip):
+# for these q | k | v come out of ONE GEMM over a stacked weight image
+FUSED_SELF_HEADS = {(128, 128), (64, 64), (32, 32), (32, 160)}
+
+
 def _no_training_dropout(mod: nn.Module, *probs: float) -> None:
     if mod.training and any(p > 0.0 for p in probs):
         raise NotImplementedError("the HIP path is forward/inference only: call .eval() or use dropout_prob=0")
@@ -148,11 +153,12 @@ class Attention(_HipModule):
                                H, dtype, two)
             d.qk = qk.desc
             keep.append(qk)
-            # q | k | v in one image when the fused attention kernel can read V row-major (per-head widths 128 / 128).
+            # q | k | v in one image when the fused attention kernel can read V row-major (the head widths it covers).
             # Under "x2s" / "x2w" the V rows alone carry a lo image (pio_linear_t.lo_row0): the wide GEMM kernel runs
             # its second K sweep for those columns only -- the library takes such an image inside the LayerNorm fold.
-            if (wlevel <= 2 and not two and self.proj_v.in_features == self.proj_q.in_features and R.pad8(dk) == 128
-                    and R.pad8(dv) == 128 and (wlevel == 0 or (2 * H * 128) % 256 == 0)):
+            if (wlevel <= 2 and not two and self.proj_v.in_features == self.proj_q.in_features
+                    and (R.pad8(dk), R.pad8(dv)) in FUSED_SELF_HEADS
+                    and (wlevel == 0 or (2 * H * R.pad8(dk)) % 256 == 0)):
                 qkv = R.PackedStack([(wt(self.proj_q), self.proj_q.bias), (wt(self.proj_k), self.proj_k.bias),
                                      (wt(self.proj_v), self.proj_v.bias)], H, dtype, [False, False, wlevel >= 1])
                 d.qkv = qkv.desc
@@ -322,11 +328,13 @@ class SelfAttention(_HipModule):
     def _build_ln_fold(self, d, a, keep, fold_ov=None):
         """LayerNorm folded into the consuming GEMMs (pio_ln_fold_t): LN(x) W^T + b = rstd (x W'^T - mean c) + b' with
         W' = W * gamma, c = rowsum(W' as packed), b' = W beta + b (reference :281-292 computes LN then Linear).
-        Offered for 1024-channel blocks under the single-sweep policies; the library decides per call."""
+        Offered for blocks of 512 / 768 / 1024 / 1280 / 1536 channels (widening factor 1) under the single-sweep policies;
+        the library decides per call."""
         dtype, wlevel, split = R.policy_dtype()
         att, mlp = self.attention, self.mlp
-        if (wlevel > 2 or split or self._in_channels != 1024 or not a.qkv.w_hi
-                or mlp.fc1.in_features != 1024 or att.proj_q.in_features != 1024):
+        C_ = self._in_channels
+        if (wlevel > 2 or split or C_ % 256 or not 512 <= C_ <= 1536 or not a.qkv.w_hi
+                or mlp.fc1.in_features != C_ or mlp.fc1.out_features != C_ or att.proj_q.in_features != C_):
             return
         with torch.no_grad():
             g1, b1 = self.layer_norm1.weight.float(), self.layer_norm1.bias.float()

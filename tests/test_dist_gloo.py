@@ -81,6 +81,11 @@ def _qworker(rank, world, port, total_q, q):
     mask = (torch.arange(total_q) % 3 != 0)[None].expand(B, total_q)
     mine, _ = shard_queries(query)
     out = decode_query_sharded(_decode_stub, query, latents, mask)      # rank / world from the process group
+    first = out.clone()
+    # a second call of the same shape must not overwrite the first result (B = 1: the transposed gather result is already
+    # contiguous, so nothing copies it out of a shared receive buffer -- the default is a fresh tensor per call)
+    out2 = decode_query_sharded(_decode_stub, query + 100.0, latents, mask)
+    assert torch.equal(out, first) and not torch.equal(out2, first)
     q.put((rank, mine.shape[1], out.numpy()))
     dist.barrier()
     dist.destroy_process_group()

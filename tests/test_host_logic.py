@@ -289,3 +289,47 @@ def test_feedback_images_are_roundings_whose_errors_cancel(dt):
         assert bool((cum.abs() <= 0.5000001 * ulp.double() * 2).all())      # (ulp doubles across a binade edge)
     plain = 8 * (w.double() - imgs[0].double()).abs()
     assert cum.abs().sum() < 0.3 * plain.sum(), "the accumulated error must be far below that of 8 equal roundings"
+
+
+def test_per_call_options_replace_the_process_wide_switches():
+    """compute calls are thread-safe per (stream, workspace).  The LayerNorm-fold switch and the CU budget
+    travel with the call (pio_call_opts_t -> thread-local inside the library for the duration of the call); the nn.Module
+    layer no longer flips pio_ln_fold_enable / pio_set_cu_budget around its calls.  CPU side: (a) the module sources hold
+    no call of the process-wide setters, (b) two threads building their per-call option blocks and descriptor arrays
+    concurrently get independent objects with the values they asked for."""
+    import inspect
+    import threading
+    from perceiverio_pytorch_amd import _lib as L
+    from perceiverio_pytorch_amd import perceiver, transformer_primitives
+    for mod in (perceiver, transformer_primitives):
+        src = inspect.getsource(mod)
+        assert "pio_ln_fold_enable(" not in src and "pio_set_cu_budget(" not in src, mod.__name__
+    assert "pio_encoder_fwd_opts" in L.SIGNATURES and "pio_self_attention_fwd_opts" in L.SIGNATURES
+    assert L.SIGNATURES["pio_encoder_fwd_opts"][1][-1]._type_ is L.CallOpts
+
+    from perceiverio_pytorch_amd.transformer_primitives import SelfAttention
+    results, errors = {}, []
+    barrier = threading.Barrier(2)
+
+    def worker(i):
+        try:
+            torch.manual_seed(i)
+            m = SelfAttention(64, widening_factor=1, num_heads=4)
+            barrier.wait(timeout=60)
+            for _ in range(50):
+                opts = L.CallOpts(1 + i, 64 * (i + 1))
+                layers = (L.SelfAttention * 2)()
+                layers[0].fold.range_flag = 1000 + i
+                assert (opts.ln_fold, opts.cu_budget) == (1 + i, 64 * (i + 1))
+                assert layers[0].fold.range_flag == 1000 + i
+            results[i] = (opts.ln_fold, opts.cu_budget, m.layer_norm1.weight.shape[0])
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=120)
+    assert not errors, errors
+    assert results == {0: (1, 64, 64), 1: (2, 128, 64)}

@@ -4,7 +4,7 @@ import pytest
 import torch
 
 import perceiver_oracle as O
-from cases import MODEL_CASES, gen_state_dict, model_inputs, model_seed
+from cases import MODEL_CASES, gen_state_dict, model_inputs, model_seed, model_stats
 from _golden import load
 
 TOL = 1e-3
@@ -45,8 +45,8 @@ def test_state_dict_layout_equals_reference(name):
     assert mine == ref
 
 
-def _load_generated(model, g, dev, seed=31):
-    params = gen_state_dict(spec_of(g), seed)
+def _load_generated(model, g, dev, seed=31, stats=None):
+    params = gen_state_dict(spec_of(g), seed, stats)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
     return model.to(dev).eval()
 
@@ -60,7 +60,7 @@ def _cached_model(name, g, dev):
     if name not in _MODELS:
         if len(_MODELS) >= 10:
             _MODELS.clear()
-        _MODELS[name] = _load_generated(build(name), g, dev, model_seed(name))
+        _MODELS[name] = _load_generated(build(name), g, dev, model_seed(name), model_stats(name))
     m = _MODELS[name]
     from perceiverio_pytorch_amd.models import DEFAULT_POLICY
     m.precision_policy = DEFAULT_POLICY[MODEL_CASES[name]["cls"]]
@@ -122,31 +122,42 @@ def test_benchmarked_path_matches_reference(name, policy):
             assert e_sd < e_16, f"{name}: fp16sd {e_sd:.3e} is not below fp16 {e_16:.3e}"
             model.precision_policy = policy
         if policy == "fp16":
-            # the fold must actually have run at B = 12 (it is what bench.py times) and, automatic, must NOT at B = 4
-            # (2048 rows: the un-folded block's smaller tiles are faster there -- pio_blocks.hip ln_fold_min_rows)
+            # the fold must actually have run at B = 12 (it is what bench.py times); at B = 4 (2048 rows) the forced
+            # setting runs it on the 256 x 256-tile kernel, the automatic one on the tile kernels (64-column statistics
+            # slots: pio_blocks.hip ln_fold_min_rows / ln_fold_small_min_rows) -- three different roundings, all held to
+            # the golden
             lib.pio_ln_fold_enable(0)
             with torch.inference_mode():
                 y0, y012 = model(x), model(x12)
             assert not torch.equal(y012, y12), "fold on/off gave identical logits: the fold did not engage at B=12"
             assert not torch.equal(y0, y), "fold forced/off gave identical logits: the fold did not engage at B=4"
+            # (un-folded plain fp16 is not a parity configuration: fp32 stream, but LayerNorm outputs rounded to 11 bits in front
+            #  of every GEMM -- 7.6e-4 / 1.05e-3 on seed 33; printed, not gated)
+            e0 = O.rel_errors(y0.cpu().numpy(), g["out"])
+            print(f"{name} [{policy}, fold off at B=4]: relL2={e0[0]:.3e} max/absmax={e0[1]:.3e}")
             lib.pio_ln_fold_enable(1)
             with torch.inference_mode():
-                assert torch.equal(model(x), y0), "automatic setting folded a 2048-row stack"
+                ya = model(x)
+            _close(ya, g["out"], f"{name} [{policy}, fold automatic at B=4: tile kernels]", tol)
+            assert not torch.equal(ya, y0) and not torch.equal(ya, y), "the tile-kernel fold did not engage at B=4"
     finally:
         lib.pio_ln_fold_enable(prev)
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("policy", ["fp16x3", "fp16x2w/fp16x2af", "fp16x2w/fp16x3f", "fp16x2w/fp16x3"])
-def test_multimodal_full_size_chunks_match_reference(policy):
+@pytest.mark.parametrize("name", ["model_multimodal_full", "model_multimodal_full_s32"])
+def test_multimodal_full_size_chunks_match_reference(name, policy):
     """BASELINE config 5 at full size (M = 52 097 x 704 single-head cross-attend, 784 x 512 latents, 6 288-row decoder
-    chunks): output chunks 0 and 127 of the reference's 128-chunk loop (multimodal_perceiver.py:146-157)."""
+    chunks): output chunks 0 and 127 (second parameter / input seed: 3 and 77) of the reference's 128-chunk loop
+    (multimodal_perceiver.py:146-157)."""
     from perceiverio_pytorch_amd.runtime import precision
-    name = "model_multimodal_full"
+    if name.endswith("_s32") and policy not in ("fp16x2w/fp16x2af", "fp16x3"):
+        pytest.skip("second seed: the class default and the fp32-grade policy")
     dev = torch.device("cuda:0")
     g = load(name)
     c = MODEL_CASES[name]
-    model = _load_generated(build(name), g, dev, model_seed(name))
+    model = _load_generated(build(name), g, dev, model_seed(name), model_stats(name))
     images, audio = [torch.from_numpy(a).to(dev) for a in model_inputs(name)]
     b, t, ch, h, w = images.shape
     ics = t * h * w // c["n_chunks"]
@@ -179,13 +190,14 @@ DENSE_OUTPUT = ("FlowPerceiver", "MultiModalPerceiver")
 @pytest.mark.gpu
 @pytest.mark.parametrize("policy", ["class default", "fp16x3", "fp16x2w", "fp16x2w/fp16x3", "fp16x2w/fp16x3f",
                                     "fp16x2w/fp16x2af", "fp16/fp16x2af", "fp16/fp16x3f"])
-@pytest.mark.parametrize("name", sorted(n for n in MODEL_CASES if n not in B4_CASES and n != "model_multimodal_full"))
+@pytest.mark.parametrize("name", sorted(n for n in MODEL_CASES if n not in B4_CASES and not n.startswith("model_multimodal_full")))
 def test_model_outputs_match_reference(name, policy):
     import perceiverio_pytorch_amd as P
     dev = torch.device("cuda:0")
     g = load(name)
     c = MODEL_CASES[name]
-    if policy == "fp16x2w" and c["cls"] in DENSE_OUTPUT and name in ("model_flow_full", "model_multimodal_small"):
+    if policy == "fp16x2w" and c["cls"] in DENSE_OUTPUT and name in ("model_flow_full", "model_flow_full_s32",
+                                                                      "model_multimodal_small"):
         pytest.skip("single-sweep decoder on a dense-output model: not a validated policy (see DENSE_OUTPUT)")
     if policy == "fp16/fp16x2af" and c["cls"] != "FlowPerceiver":
         pytest.skip("single-sweep fp16 encoder: validated for the flow model only (its class default)")
@@ -195,8 +207,10 @@ def test_model_outputs_match_reference(name, policy):
         pytest.skip("the class default of the dense-output models is in the explicit list")
     if name in ("model_language_s32", "model_language_s33") and policy not in ("class default", "fp16x2w", "fp16/fp16x3f"):
         pytest.skip("extra language seeds: the shipped policies only")
+    if name == "model_flow_full_s32" and policy not in ("fp16/fp16x2af", "fp16x3"):
+        pytest.skip("second flow seed: the class default and the fp32-grade policy")
     model = (_cached_model(name, g, dev) if c["cls"] == "LanguagePerceiver"
-             else _load_generated(build(name), g, dev, model_seed(name)))
+             else _load_generated(build(name), g, dev, model_seed(name), model_stats(name)))
     if policy != "class default":
         model.precision_policy = policy        # overrides the per-class default (models.DEFAULT_POLICY)
     else:
@@ -205,7 +219,7 @@ def test_model_outputs_match_reference(name, policy):
     ins = [torch.from_numpy(a).to(dev) for a in model_inputs(name)]
     tol = TOL if policy != "fp16x3" else 1e-4
     with torch.inference_mode():
-        if name == "model_flow_full":
+        if name.startswith("model_flow_full"):
             # maximum size of the shipped models: 182 528 input tokens AND 182 528 decoder queries; the reference
             # materialises two 1.5 GB score matrices for this.  Compared on an 8x sub-sampled grid, errors relative
             # to the whole field's magnitude (stored with the golden).
