@@ -27,7 +27,7 @@ Rank 0 prints ONE JSON line.  Extra objects:
   parity       -- in-run check of the benchmarked policy against REFERENCE goldens (gate 1e-3): for imagenet the
                   B = 4 golden, whose 2048 latent rows take the same LayerNorm-fold path as the timed batch
   class_default_policy -- (imagenet) the same step under the class-default policy of ClassificationPerceiver
-  margin_2x_policy     -- (imagenet) the same step under fp16x2s, the fastest policy that meets 1e-3 with a 2x margin
+  single_sweep_policy  -- (imagenet) the same step under fp16sd everywhere (round 3's headline; fails a trained-like golden)
 """
 from __future__ import annotations
 
@@ -60,7 +60,11 @@ CONFIGS = {
                      # "fp16sd": single-sweep fp16 with error-feedback rounding of the weights the 8 blocks share (one packed
                      # image set per block; same kernels and time as "fp16", worst golden 6.6e-4 / 7.3e-4 against 7.7e-4 /
                      # 8.2e-4 -- runtime.py _POLICIES, tools/sd_parity.py)
-                     batch=32, policy="fp16sd",
+                     # round 4: the headline runs the CLASS DEFAULT -- "fp16sd" alone fails one of the two goldens with trained-like
+                     # parameter statistics (8.3e-4 / 1.72e-3); the default splits the weights of the encoder's cross-attend and
+                     # both operands of the decoder (weights applied once, 1.2 of 16 ms) around the single-sweep fp16sd stack:
+                     # worst of eight goldens 5.6e-4 / 5.8e-4 (models.py DEFAULT_POLICY, tools/r4_policy_table.py)
+                     batch=32, policy="fp16x2w/fp16sd/fp16x3f",
                      gflop=381.65, scaling="weak",
                      metric="samples/sec PerceiverIO fwd (ImageNet-224, 512x1024 latents, 8 blocks x 6 self-attends)",
                      workload="imagenet224 ClassificationPerceiver (conv+Fourier prep -> encoder 3136x322->512x1024, "
@@ -92,7 +96,7 @@ CONFIGS = {
                              decoder_query_residual=False, final_project=True),
                  hot=dict(M=182528, C=322, Q=182528)),
     "multimodal": dict(golden="model_multimodal_full", parity_golden="model_multimodal_full", batch=1,
-                       policy="fp16x2w/fp16x2af",
+                       policy="fp16x2w/fp16x3f",
                        gflop=250.1 + 128 * 57.2, scaling="weak",
                        metric="samples/sec PerceiverIO fwd (multimodal autoencode, 16x224x224 video + audio + label, "
                               "784x512 latents, 128 output chunks)",
@@ -734,7 +738,7 @@ def main():
             from perceiverio_pytorch_amd.models import DEFAULT_POLICY
             dflt = DEFAULT_POLICY["ClassificationPerceiver"]
             other = {}
-            for pol in ([dflt, "fp16sd/fp16x3f", "fp16"] if not args.hot_path_only else []):
+            for pol in ([dflt, "fp16sd", "fp16"] if not args.hot_path_only else []):
                 if pol == policy or pol in other:
                     continue
                 model.precision_policy = pol
@@ -748,7 +752,7 @@ def main():
                                             "ok": pp["ok"]}
             model.precision_policy = policy
             class_default = other.get(dflt)
-            robust = other.get("fp16sd/fp16x3f")
+            robust = other.get("fp16sd")
             plain16 = other.get("fp16")
 
     ms_per_step = elapsed / steps * 1e3
@@ -815,11 +819,10 @@ def main():
     if class_default is not None:
         out["class_default_policy"] = class_default
     if robust is not None:
-        # the decoder with split operands around its fused core ("fp16x3f"), everything else as the headline policy:
-        # 4.2e-4 / 5.0e-4 on the worst of the six goldens -- the policy to quote if the 1e-3 bar must hold with a 2x margin
-        # (the headline policy "fp16sd" sits at 6.6e-4 / 7.3e-4, plain "fp16" at 7.7e-4 / 8.2e-4; the class default
-        # "fp16x3f/fp16sd/fp16x3f" at 3.2e-4 / 3.9e-4)
-        out["margin_2x_policy"] = robust
+        # round 3's headline policy, for the record: the stack's "fp16sd" everywhere (single-sweep cross-attends).  It holds
+        # on the six initialiser-like goldens (6.6e-4 / 7.3e-4) and FAILS one of the two with trained-like parameter
+        # statistics (8.3e-4 / 1.72e-3) -- its "parity.ok" says so; not a parity configuration any more
+        out["single_sweep_policy"] = robust
     if plain16 is not None:
         out["plain_fp16_policy"] = plain16       # one image per shared weight (round-to-nearest): same launches
     if rank == 0 and world == 1:

@@ -565,9 +565,18 @@ int gemm_nt_launch(const pio_gemm_t &g, hipStream_t s) {
         p.tiles_n = (p.n_store + 63) / 64;
         grid = dim3((unsigned)(((g.M + 63) / 64) * p.tiles_n), (unsigned)g.batch, 1);
     }
+    // 128 x 128 tiles on problems of at most ONE workgroup per CU (nobody covers a wave's wait for its next operand
+    // stage): the four-stage LDS-DMA ring instead of the double buffer -- measured level on the flow stack's q|k|v GEMM
+    // (2048 x 1536 x 512: 5.69 -> 5.68 ms per forward) and not better anywhere, so opt-in (env PIO_GEMM_RING128=1)
+    static const bool ring128_on = [] {
+        const char *e = getenv("PIO_GEMM_RING128");
+        return e && atoi(e) != 0;
+    }();
+    const bool ring128 = !small && ring128_on && tiles128 <= cu_budget();
 #define PIO_G128(DTV, KINDV)                                                                            \
     do {                                                                                                \
         if (small) hipLaunchKernelGGL((gemm_nt_128<DTV, KINDV, 64, 64, 4>), grid, block, 0, s, p);      \
+        else if (ring128) hipLaunchKernelGGL((gemm_nt_128<DTV, KINDV, 128, 128, 4>), grid, block, 0, s, p); \
         else hipLaunchKernelGGL((gemm_nt_128<DTV, KINDV, 128, 128, 2>), grid, block, 0, s, p);          \
     } while (0)
     if (g.dtype == PIO_DT_F16) {

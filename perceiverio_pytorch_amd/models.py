@@ -46,8 +46,19 @@ from .position_encoding import PosEncodingType
 # The language model (26 distinct layers: nothing to feed back over) keeps split weights for proj_v / final in the stack
 # ("fp16x2s") and takes the same split-operand cross-attends: 3.7e-4 / 3.9e-4 at 27.6 ms for B = 100 against "fp16x2w"
 # 3.8e-4 / 4.8e-4 at 28.4 ms; "fp16/fp16x3f" (single-sweep stack) passes the bar at 6.4e-4 / 8.7e-4 and 22.8 ms.
-DEFAULT_POLICY = {"ClassificationPerceiver": "fp16x3f/fp16sd/fp16x3f", "LanguagePerceiver": "fp16x3f/fp16x2s/fp16x3f",
-                  "FlowPerceiver": "fp16/fp16x2af", "MultiModalPerceiver": "fp16x2w/fp16x2af"}
+# Round 4 widened what the margins are measured on (oracle/cases.py: two classifier goldens with TRAINED-LIKE parameter
+# statistics -- log-normal weight-row scales over a decade, LayerNorm gains in [0.2, 5], outlier channels -- and a second
+# parameter / input seed for each dense-output model at full size) and two defaults moved (tools/r4_policy_table.py):
+#  * classifier: "fp16sd" alone FAILS the trained-like golden on natural-image inputs (8.3e-4 / 1.72e-3); with the decoder
+#    split ("fp16sd/fp16x3f") 6.7e-4 / 1.23e-3; the heavy-tailed rows sit in the two cross-attends.  Eight goldens, worst
+#    case: "fp16x3f/fp16sd/fp16x3f" 4.9e-4 / 6.6e-4 at +7.4 % time over "fp16sd"; "fp16x2w/fp16sd/fp16x3f" (the encoder's
+#    cross-attend with split WEIGHTS only: two sweeps instead of three) 5.6e-4 / 5.8e-4 at +4.8 % -- the default now;
+#    "fp16x2w/fp16sd/fp16x2af" 6.5e-4 / 7.0e-4 at +2.7 %, "fp16x2w/fp16sd/fp16x2w" 6.5e-4 / 9.5e-4 at +2.3 %.
+#  * multimodal: "fp16x2w/fp16x2af" holds on seed 31 (3.9e-4 / 4.8e-4) and FAILS seed 32 (1.01e-3 / 1.14e-3: there the
+#    rounding of the decoder's WEIGHTS dominates, on seed 31 that of its activations -- "x2w" decoders fail seed 31 at
+#    1.3e-3); with both split ("fp16x2w/fp16x3f") 0.6e-4 / 2.7e-4 on both -- the default now, +17 % time.
+DEFAULT_POLICY = {"ClassificationPerceiver": "fp16x2w/fp16sd/fp16x3f", "LanguagePerceiver": "fp16x3f/fp16x2s/fp16x3f",
+                  "FlowPerceiver": "fp16/fp16x2af", "MultiModalPerceiver": "fp16x2w/fp16x3f"}
 
 
 def split_policy3(policy):
