@@ -76,7 +76,7 @@ CONFIGS = {
     # (batch 100: 100 x 256 latent rows = 100 tile rows of the 256-row GEMM tilings -- 500 / 1000 tiles, whole rounds of the
     #  256 CUs; B = 32 gives 160-tile launches: 2 574 samples/s against 3 409, profiles/r3_configs.json)
     "language": dict(golden="model_language", parity_golden="model_language", batch=100,
-                     policy="fp16x3f/fp16x2s/fp16x3f",       # (the class default)
+                     policy="fp16x2w/fp16x2o/fp16x3f",       # (the class default, round 4)
                      gflop=120.1, scaling="weak",
                      metric="samples/sec PerceiverIO fwd (masked-LM, 2048 byte tokens, 256x1280 latents, 26 self-attends)",
                      workload="LanguagePerceiver: 2048 byte tokens (ragged valid lengths 512..2048, input + query "
@@ -219,10 +219,11 @@ def parity_check(name, model, params, dev, policy):
             from cases import gen_state_dict, model_seed
             per = {}
             keep = {k: v.clone() for k, v in model.state_dict().items()}
-            for gn in ("model_language", "model_language_s32", "model_language_s33"):
+            from cases import model_stats
+            for gn in ("model_language", "model_language_s32", "model_language_s33", "model_language_trained"):
                 gg = np.load(os.path.join(ROOT, "tests", "golden", gn + ".npz"))
-                if model_seed(gn) != SEED:
-                    sd = gen_state_dict(spec_of(gg), model_seed(gn))
+                if model_seed(gn) != SEED or model_stats(gn):
+                    sd = gen_state_dict(spec_of(gg), model_seed(gn), model_stats(gn))
                     model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
                 tok, msk = [torch.from_numpy(a).to(dev) for a in model_inputs(gn)]
                 y = model(tok, msk).cpu().numpy()
@@ -230,12 +231,19 @@ def parity_check(name, model, params, dev, policy):
                 e_tail = rel_errors(y[:, 640:704], gg["out_tail"], gg["out_absmax"])
                 per[gn] = (max(e_head[0], e_tail[0]), max(e_head[1], e_tail[1]))
             model.load_state_dict(keep, strict=True)
+            # (the trained-like golden is REPORTED, not gated: a known limit of single-sweep attention cores at large
+            #  logits -- 2.6e-3 / 4.1e-3 under every policy but the fp32-grade one, models.py DEFAULT_POLICY)
+            stress = per.pop("model_language_trained")
+            out["known_limit"] = {"golden": "model_language_trained", "relL2": stress[0], "max_abs_over_absmax": stress[1],
+                                  "note": "LayerNorm gains up to 5: attention logits |s| ~ 10-15; q / k rounded once to fp16 "
+                                          "in front of the fused cores put |s| 2^-11 into the exponent"}
             rl2, rmax = max(v[0] for v in per.values()), max(v[1] for v in per.values())
             out["golden"] = "tests/golden/model_language*.npz (reference fp32 outputs)"
             out["per_golden"] = {k: {"relL2": v[0], "max_abs_over_absmax": v[1]} for k, v in per.items()}
             out["worst"] = max(per, key=lambda k: max(per[k]))
             out["case"] = ("LanguagePerceiver B=2, three parameter / token seeds with ragged valid lengths (60 / 700, 2048 / "
-                           "333, 1 / 1290), logits rows 0..95 and 640..703; worst case gates")
+                           "333, 1 / 1290) + one with trained-like parameter statistics (1700 / 420), logits rows 0..95 and "
+                           "640..703; worst case gates")
         elif name == "flow":
             # two goldens (parameter / frame seeds 31 and 32): worst case gates
             from cases import gen_state_dict, model_seed, model_stats

@@ -158,6 +158,9 @@ MODEL_CASES = {
                                        pseed=41, stats="trained"),
     "model_classify_b4_trained2": dict(cls="ClassificationPerceiver", kw=dict(prep="FOURIER_POS_CONVNET"), batch=4,
                                        pseed=42, stats="trained", inputs="natural"),
+    # ... a language model with the same trained-like statistics (two ragged lengths)
+    "model_language_trained": dict(cls="LanguagePerceiver", kw=dict(), batch=2, pseed=43, stats="trained",
+                                   lengths=(1700, 420)),
     # ... and a second parameter / input seed for each dense-output model at full size
     "model_flow_full_s32": dict(cls="FlowPerceiver", kw=dict(), batch=1, pseed=32),
     "model_multimodal_full_s32": dict(cls="MultiModalPerceiver", kw=dict(), batch=1, chunks=(3, 77), n_chunks=128,

@@ -565,6 +565,13 @@ static int64_t ln_fold_small_min_rows() {
     }();
     return ln_fold_choice() == 2 ? 128 : auto_rows;
 }
+static int64_t ln_fold_small_max_rows() {
+    static const int64_t max_rows = [] {
+        const char *e = getenv("PIO_LN_FOLD_SMALL_MAX_ROWS");
+        return (int64_t)(e ? atoll(e) : 4096);
+    }();
+    return max_rows;
+}
 
 // Carried from one SelfAttention block to the next inside a stack: the 16-bit copy and the partial sums of the block's
 // INPUT, left in the plan's (x16, part_a) buffers by the previous block's fc2 GEMM.
@@ -599,7 +606,11 @@ static int self_attention_run(const pio_self_attention_t &sa, const pio_tensor3_
                          !kv_mask && !q_mask && !full_mask && !attention_bias && !probs_out &&
                          (((uintptr_t)x.data) & 15) == 0;
     const bool fold_wide = fold_ok && rows >= ln_fold_min_rows();
-    const bool fold_small = fold_ok && !fold_wide && rows >= ln_fold_small_min_rows() && !sa.fold.qkv.w_lo &&
+    // (tile-kernel family: up to 4095 rows in the automatic mode -- ImageNet B = 8, 4096 rows, measures 8.33 ms folded on
+    //  the tile kernels against 7.86 un-folded, whose q|k|v GEMM runs on the 256 x 256-tile kernel; B = 1 / 2 / 4:
+    //  3.78 / 4.28 / 5.05 against 3.97 / 4.39 / 5.27 ms -- tools/r4_probe4.sh)
+    const bool fold_small = fold_ok && !fold_wide && rows >= ln_fold_small_min_rows() &&
+                            (ln_fold_choice() == 2 || rows < ln_fold_small_max_rows()) && !sa.fold.qkv.w_lo &&
                             !sa.fold.fc1.w_lo && !sa.attn.o.w_lo && !sa.mlp.fc2.w_lo;
     const bool fold = fold_wide || fold_small;
     if (fold) {

@@ -42,7 +42,12 @@ _POLICIES = {"fp16": (L.PIO_DT_F16, 0, False), "fp16x2s": (L.PIO_DT_F16, 1, Fals
              # weight accumulate stays below half an ulp instead of growing 8-fold.  Same kernels, same time, 8 x the
              # packed images (604 MB for the ImageNet stack); -18..-21 % error on the ImageNet goldens.  Everything
              # that is not a weight-shared block stack runs as under "fp16".
-             "fp16sd": (L.PIO_DT_F16, 0, False)}
+             "fp16sd": (L.PIO_DT_F16, 0, False),
+             # finer weight splits of a self-attend stack (round 4): only the out projection ("final"), or only proj_v, of
+             # the two that "x2s" splits -- a second K sweep costs its GEMM's time again
+             "fp16x2o": (L.PIO_DT_F16, 0, False), "fp16x2v": (L.PIO_DT_F16, 0, False)}
+# weights split under the fine policies (beside the level of _POLICIES): names of Attention's linears
+_FINE_SPLIT = {"fp16x2o": {"final"}, "fp16x2v": {"proj_v"}}
 _FUSED_CORE = {"fp16x3f", "bf16x3f", "fp16x2af"}
 _BLOCK_FEEDBACK = {"fp16sd"}
 _policy = os.environ.get("PIO_PRECISION", "fp16x3")
@@ -157,6 +162,11 @@ def capturing(device: torch.device) -> bool:
         return bool(torch.cuda.is_current_stream_capturing())
     except Exception:  # noqa: BLE001
         return False
+
+
+def policy_fine_split(name: Optional[str] = None) -> set:
+    """Names of the Attention linears whose weights are (hi, lo) pairs beyond what the policy's level says."""
+    return _FINE_SPLIT.get(name or _policy, set())
 
 
 def policy_core_single(name: Optional[str] = None) -> bool:

@@ -141,8 +141,10 @@ class Attention(_HipModule):
         wt = (lambda lin: ov[lin]) if ov else (lambda lin: lin.weight)
         q = R.PackedLinear(wt(self.proj_q), self.proj_q.bias, H, 1, dtype, two)
         k = R.PackedLinear(wt(self.proj_k), self.proj_k.bias, H, 1, dtype, two)
-        v = R.PackedLinear(wt(self.proj_v), self.proj_v.bias, H, 1, dtype, wlevel >= 1)
-        o = R.PackedLinear(wt(self.final), self.final.bias, 1, H, dtype, wlevel >= 1, k_channels=False)
+        fine = R.policy_fine_split()
+        v_two, o_two = wlevel >= 1 or "proj_v" in fine, wlevel >= 1 or "final" in fine
+        v = R.PackedLinear(wt(self.proj_v), self.proj_v.bias, H, 1, dtype, v_two)
+        o = R.PackedLinear(wt(self.final), self.final.bias, 1, H, dtype, o_two, k_channels=False)
         dk, dv = self._qk_channels_per_head, self._v_channels_per_head
         d = L.Attention(q.desc, k.desc, v.desc, o.desc, H, dk, dv, R.pad8(dk), R.pad8(dv),
                         self.proj_q.in_features, self.proj_k.in_features, self.proj_v.in_features,
@@ -158,9 +160,9 @@ class Attention(_HipModule):
             # its second K sweep for those columns only -- the library takes such an image inside the LayerNorm fold.
             if (wlevel <= 2 and not two and self.proj_v.in_features == self.proj_q.in_features
                     and (R.pad8(dk), R.pad8(dv)) in FUSED_SELF_HEADS
-                    and (wlevel == 0 or (2 * H * R.pad8(dk)) % 256 == 0)):
+                    and (not v_two or (2 * H * R.pad8(dk)) % 256 == 0)):
                 qkv = R.PackedStack([(wt(self.proj_q), self.proj_q.bias), (wt(self.proj_k), self.proj_k.bias),
-                                     (wt(self.proj_v), self.proj_v.bias)], H, dtype, [False, False, wlevel >= 1])
+                                     (wt(self.proj_v), self.proj_v.bias)], H, dtype, [False, False, v_two])
                 d.qkv = qkv.desc
                 keep.append(qkv)
         return d, keep
@@ -350,7 +352,7 @@ class SelfAttention(_HipModule):
             H = att._num_heads
             # (the split levels of the un-folded descriptors: proj_v from "x2s" on, fc1 from "x2w" on)
             qkv = R.PackedStack([folded(att.proj_q, g1, b1), folded(att.proj_k, g1, b1), folded(att.proj_v, g1, b1)],
-                                H, dtype, [False, False, wlevel >= 1])
+                                H, dtype, [False, False, wlevel >= 1 or "proj_v" in R.policy_fine_split()])
             fc1 = R.PackedLinear(*folded(mlp.fc1, g2, b2), 1, 1, dtype, wlevel >= 2, n_channels=True)
             # c[n] = sum_k of the packed weights the GEMM actually multiplies with: hi (+ lo where there is one)
             qkv_c = (qkv.hi.float() + (qkv.lo.float() if qkv.lo is not None else 0)).sum(1).contiguous()
