@@ -88,8 +88,16 @@ typedef struct pio_attention_t {
                           score matrix) and returns its output as a pair                                      */
     pio_linear_t qk;   /* optional (w_hi may be NULL): proj_q and proj_k stacked along the output rows
                           [q rows | k rows], used as ONE GEMM when inputs_q and inputs_k are the same tensor */
-    pio_linear_t qkv;  /* optional (w_hi may be NULL): [q rows | k rows | v rows] for self-attention with
-                          dkp == dvp == 128: one GEMM, V consumed row-major by the fused attention kernel */
+    pio_linear_t qkv;  /* optional (w_hi may be NULL): [q rows | k rows | v rows] for self-attention with head widths
+                          the fused kernel covers: one GEMM, V consumed row-major by the fused attention kernel */
+    /* Optional K / V projection fold of a SINGLE-HEAD cross-attend over many keys (both w_hi non-NULL; SURVEY.md section 7,
+     * transformer_primitives.py:93-95,138,163): q (x Wk^T + bk)^T = (q Wk) x^T + const, and P (x Wv^T + bv) Wo^T + bo =
+     * (P x) (Wo Wv)^T + (Wo bv + bo) because softmax rows sum to one.  kq = Wk^T packed as a linear [k_in <- qk] without
+     * bias (Q' = Q Wk), vo = Wo Wv packed [out <- v_in] with bias Wo bv + bo.  The fused kernel then reads the
+     * LayerNorm'd inputs themselves as K and (transposed) as V: the two [keys, C] x [C, C] projection GEMMs vanish.
+     * Taken when heads == 1, dk == dv == k_in == v_in, inputs_k is inputs_v, no full mask / bias / probabilities, and
+     * keys outnumber query rows at least 4 : 1. */
+    pio_linear_t kq, vo;
 } pio_attention_t;
 
 /* MLP (transformer_primitives.py:183-216) */

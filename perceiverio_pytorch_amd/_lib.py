@@ -39,7 +39,7 @@ class Attention(C.Structure):
     _fields_ = [("q", Linear), ("k", Linear), ("v", Linear), ("o", Linear), ("heads", C.c_int32),
                 ("dk", C.c_int32), ("dv", C.c_int32), ("dkp", C.c_int32), ("dvp", C.c_int32),
                 ("q_in", C.c_int32), ("k_in", C.c_int32), ("v_in", C.c_int32), ("out", C.c_int32), ("dtype", C.c_int32),
-                ("act_split", C.c_int32), ("qk", Linear), ("qkv", Linear)]
+                ("act_split", C.c_int32), ("qk", Linear), ("qkv", Linear), ("kq", Linear), ("vo", Linear)]
 
 
 class Mlp(C.Structure):

@@ -222,6 +222,13 @@ static int check_attention(const pio_attention_t &a) {
     return PIO_OK;
 }
 
+// K / V projection fold of the single-head cross-attends (attention_core step 0b); PIO_KV_FOLD=0 turns it off (read at
+// every call: an A/B switch for tools/, not an API).
+static bool kv_fold_enabled() {
+    const char *e = getenv("PIO_KV_FOLD");
+    return !e || atoi(e) != 0;
+}
+
 static int attention_core(const pio_attention_t &a, Pair xq, bool q_bcast, Pair xk, Pair xv, int B, int Tq, int Tk,
                           const uint8_t *kv_mask, const uint8_t *q_mask, const uint8_t *full_mask,
                           const float *attention_bias, const Residual *res, float *out, float *probs_out,
@@ -261,6 +268,33 @@ static int attention_core(const pio_attention_t &a, Pair xq, bool q_bcast, Pair 
                               fold_out);
         }
         if (fold_in || fold_out) return PIO_E_SHAPE;  // the fold is wired into the fused q|k|v form only
+    }
+
+    // 0b: K / V projection fold of a single-head cross-attend over many keys (pio_attention_t.kq / vo):
+    //     scores = (Q Wk) x^T (+ a per-query constant the softmax cancels), output = (P x)(Wo Wv)^T + (Wo bv + bo).  The fused
+    //     kernel reads the LayerNorm'd input array itself as K and its transpose as V^T: the two [keys, C] x [C, C]
+    //     projection GEMMs and their 16-bit round trip are gone; what is left per call is Q' = Q Wk (query rows only),
+    //     one 16-bit transpose of the inputs and the out projection over K = C.
+    {
+        const int kvp = pad8(a.k_in);
+        const bool kv_fold = kv_fold_enabled() && a.kq.w_hi && a.vo.w_hi && H == 1 && a.k_in == a.v_in && xk.hi == xv.hi &&
+                             a.dk == a.k_in && a.dv == a.v_in && a.dkp == kvp && a.dvp == kvp && a.act_split != 1 &&
+                             !full_mask && !attention_bias && !probs_out && xattn_supported(kvp, kvp) &&
+                             a.kq.k == hdk && a.kq.n == kvp && a.vo.k == kvp && (int64_t)B * Tk >= 4 * (int64_t)Bq * Tq &&
+                             !fold_in && !fold_out;
+        if (kv_fold) {
+            const bool single_core = a.act_split == 2;
+            // Q = LN_q(xq) Wq^T + bq (as always), then Q' = Q Wk into the (otherwise unused) k16 scratch
+            PIO_TRY(linear_fwd(a.q, a.dtype, xq, (int64_t)Bq * Tq, w.q16.hi, w.q16.lo, false, 0, hdk, 0, nullptr, s));
+            PIO_TRY(linear_fwd(a.kq, a.dtype, w.q16, (int64_t)Bq * Tq, w.k16.hi, w.k16.lo, false, 0, kvp, 0, nullptr, s));
+            const int64_t ldx = padc(a.k_in);      // row pitch of the LayerNorm'd inputs
+            PIO_TRY(transpose16_launch(xk.hi, ldx, B, Tk, kvp, w.vt16.hi, tkv, s));
+            PIO_TRY(xattn_launch(a.dtype, kvp, kvp, a.dk, w.k16.hi, xk.hi, w.vt16.hi, w.o16.hi,
+                                 single_core ? w.o16.lo : nullptr, B, H, Tq, Tk, kvp, ldx, tkv, kvp,
+                                 q_bcast ? 0 : (int64_t)Tq * kvp, (int64_t)Tk * ldx, (int64_t)kvp * tkv, (int64_t)Tq * kvp,
+                                 kv_mask, q_mask, w.xpart, s));
+            return linear_fwd(a.vo, a.dtype, w.o16, (int64_t)B * Tq, out, nullptr, true, a.out, out_ld, 0, res, s);
+        }
     }
 
     // 1/2: Q and K projections (transformer_primitives.py:93-94), head-padded columns.  When both read the same

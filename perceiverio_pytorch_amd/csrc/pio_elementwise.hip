@@ -289,6 +289,47 @@ int rowstats_cast_launch(const float *x, int64_t rows, int C, int slot_w, void *
     return launch_status();
 }
 
+// V^T[b][c][t] = X[b][t][c] for a 16-bit array (K / V projection fold of a single-head cross-attend: the LayerNorm'd
+// inputs themselves are the values, consumed K-contiguous): X [B][T][ldx] -> VT [B][C][tkv], columns t in [T, tkv) zero.
+// 64 x 64 tiles through LDS, 16-byte accesses on both sides (C % 8 == 0, ldx % 8 == 0, tkv % 8 == 0).
+__global__ __launch_bounds__(256) void transpose16_kernel(const uint16_t *__restrict__ x, int64_t ldx, int T, int C,
+                                                          uint16_t *__restrict__ vt, int64_t tkv) {
+    __shared__ uint16_t tile[64][72];  // (+8: the transposed reads walk a column)
+    const int b = blockIdx.z, t0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    const int tid = threadIdx.x;
+    const uint16_t *xb = x + (int64_t)b * T * ldx;
+    typedef uint16_t u16x8 __attribute__((ext_vector_type(8)));
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int r = it * 32 + (tid >> 3), ch = (tid & 7) * 8;
+        u16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (t0 + r < T && c0 + ch < C) v = *(const u16x8 *)(xb + (int64_t)(t0 + r) * ldx + c0 + ch);
+        *(u16x8 *)&tile[r][ch] = v;
+    }
+    __syncthreads();
+    uint16_t *vb = vt + (int64_t)b * C * tkv;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int c = it * 32 + (tid >> 3), tc = (tid & 7) * 8;
+        if (c0 + c < C && t0 + tc < tkv) {
+            u16x8 v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = tile[tc + e][c];
+            *(u16x8 *)(vb + (int64_t)(c0 + c) * tkv + t0 + tc) = v;
+        }
+    }
+}
+
+int transpose16_launch(const void *x, int64_t ldx, int B, int T, int C, void *vt, int64_t tkv, hipStream_t s) {
+    if (!x || !vt || B <= 0 || T <= 0 || C <= 0) return PIO_E_ARG;
+    if ((C & 7) || (ldx & 7) || (tkv & 7) || tkv < T || B > 65535) return PIO_E_SHAPE;
+    if (((uintptr_t)x & 15) || ((uintptr_t)vt & 15)) return PIO_E_ALIGN;
+    ProfScope prof(PROF_LAYERNORM, 0.0, 2.0 * B * (double)T * C * 2.0, s);
+    dim3 grid((unsigned)((tkv + 63) / 64), (unsigned)((C + 63) / 64), (unsigned)B);
+    hipLaunchKernelGGL(transpose16_kernel, grid, dim3(256), 0, s, (const uint16_t *)x, ldx, T, C, (uint16_t *)vt, tkv);
+    return launch_status();
+}
+
 // The same with 8-byte (float2) accesses for even channel counts whose rows are only 8-byte aligned -- the 322-wide
 // encoder input array [B, 3136, 322]: 129 MB at B = 32, the largest single read of the model.
 template <int DT, bool NORM>

@@ -109,6 +109,8 @@ int layernorm_cast_cat_launch(const pio_tensor3_t &x1, const pio_tensor3_t &x2, 
 // producing GEMM)
 int rowstats_cast_launch(const float *x, int64_t rows, int C, int slot_w, void *y16, void *y16_lo, float *part, int dtype,
                          hipStream_t s);
+// VT[b][c][t] = X[b][t][c] (16-bit; columns t in [T, tkv) zero): the values of a K / V-folded cross-attend
+int transpose16_launch(const void *x, int64_t ldx, int B, int T, int C, void *vt, int64_t tkv, hipStream_t s);
 int ln_fold_enable(int on);   // returns the previous setting
 bool ln_fold_enabled();
 int softmax_rows_launch(const float *S, int64_t lds, void *P, void *P_lo, int64_t ldp, int B, int H, int Tq, int Tk,

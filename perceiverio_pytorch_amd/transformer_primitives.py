@@ -150,6 +150,27 @@ class Attention(_HipModule):
                         self.proj_q.in_features, self.proj_k.in_features, self.proj_v.in_features,
                         self.final.out_features, dtype, (2 if R.policy_core_single() else 1) if split else 0)
         keep = [q, k, v, o]
+        # K / V projection fold of a single-head cross-attend (pio_attention_t.kq / vo; SURVEY.md section 7 "legal algebraic
+        # restructurings", reference :93-95,138,163): q (x Wk^T + bk)^T = (q Wk) x^T + const and
+        # P (x Wv^T + bv) Wo^T + bo = (P x)(Wo Wv)^T + (Wo bv + bo).  The folded weights are formed in float64 and packed
+        # like any other; the library takes them when keys outnumber query rows 4 : 1 (the encoders' cross-attends).
+        # Offered under the single-weight policies only ("fp16", "fp16sd", "fp16x2af"): there it replaces single-sweep K / V
+        # projections with exact (float64-folded, pair-packed) weights -- on the eight classifier goldens "fp16sd" moves from
+        # 8.3e-4 / 1.72e-3 (fails the trained-like one) to 7.7e-4 / 9.0e-4, the multimodal model under "fp16/fp16x3f" from
+        # 9.7e-4 / 1.06e-3 to 5.4e-4 / 5.6e-4, the flow forward from 5.66 to 5.42 ms.  Under the split-weight policies the
+        # un-folded projections (K rounded AFTER an exact product) stay: 5.5e-4 / 5.8e-4 against 6.0e-4 / 8.4e-4 folded --
+        # Q Wk concentrates on the outlier columns of a heavy-tailed Wk and multiplies the rounding of x there.
+        kin = self.proj_k.in_features
+        if H == 1 and kin == self.proj_v.in_features and dk == kin and dv == kin and wlevel == 0:
+            with torch.no_grad():
+                Wk, Wv, Wo = wt(self.proj_k).double(), wt(self.proj_v).double(), wt(self.final).double()
+                bv = self.proj_v.bias.double() if self.proj_v.bias is not None else torch.zeros(kin, device=Wv.device)
+                bo = self.final.bias.double() if self.final.bias is not None else 0.0
+                kq = R.PackedLinear(Wk.t().float().contiguous(), None, 1, 1, dtype, True, k_channels=False)
+                vo = R.PackedLinear((Wo @ Wv).float().contiguous(), (Wo @ bv + bo).float().contiguous(), 1, 1, dtype,
+                                    True, k_channels=False)
+            d.kq, d.vo = kq.desc, vo.desc
+            keep += [kq, vo]
         if self.proj_q.in_features == self.proj_k.in_features and not split:
             qk = R.PackedStack([(wt(self.proj_q), self.proj_q.bias), (wt(self.proj_k), self.proj_k.bias)],
                                H, dtype, two)
