@@ -95,7 +95,7 @@ typedef struct pio_attention_t {
      * (P x) (Wo Wv)^T + (Wo bv + bo) because softmax rows sum to one.  kq = Wk^T packed as a linear [k_in <- qk] without
      * bias (Q' = Q Wk), vo = Wo Wv packed [out <- v_in] with bias Wo bv + bo.  The fused kernel then reads the
      * LayerNorm'd inputs themselves as K and (transposed) as V: the two [keys, C] x [C, C] projection GEMMs vanish.
-     * Taken when heads == 1, dk == dv == k_in == v_in, inputs_k is inputs_v, no full mask / bias / probabilities, and
+     * Taken when heads == 1, dk == dv == k_in == v_in, inputs_k is inputs_v, no mask / bias / probabilities, and
      * keys outnumber query rows at least 4 : 1. */
     pio_linear_t kq, vo;
 } pio_attention_t;
@@ -302,6 +302,15 @@ int pio_gemm_nt(const pio_gemm_t *g, void *stream);
 int pio_softmax_rows(const float *S, int64_t lds, void *P, void *P_lo, int64_t ldp, int32_t B, int32_t H,
                      int32_t Tq, int32_t Tk, float scale, const uint8_t *kv_mask, const uint8_t *q_mask,
                      const uint8_t *full_mask, const float *bias, int32_t dtype, void *stream);
+
+/* O = softmax(Q K^T / sqrt(dk)) V without the score matrix in HBM, un-masked (transformer_primitives.py:138-166 for the
+ * latent self-attention): 16-bit Q [B][Tq][.. h*dkp ..] (row stride ldq, batch stride sQb elements), K likewise, V either
+ * K-contiguous V^T [B][H*dvp][keys] (row stride ldv) or -- v_rowmajor != 0 -- row-major [B][Tk][.. h*dvp ..] (the layout ONE
+ * fused q|k|v GEMM writes), O [B][Tq][.. h*dvp ..].  (dkp, dvp) in {(128,128), (64,64), (32,32), (32,160)}; dk = the logical
+ * per-head width the scale uses.  The kernel the SelfAttention blocks run; exposed for tests and tools/r4_ceiling.py. */
+int pio_flash_attention(int32_t dtype, int32_t dkp, int32_t dvp, int32_t dk, const void *Q, const void *K, const void *V,
+                        void *O, int32_t B, int32_t H, int32_t Tq, int32_t Tk, int64_t ldq, int64_t ldk, int64_t ldv,
+                        int64_t ldo, int64_t sQb, int64_t sKb, int64_t sVb, int64_t sOb, int32_t v_rowmajor, void *stream);
 
 /* --- blocks: the reference's nn.Module.forward calls ------------------------------------------ */
 /* Attention.forward (transformer_primitives.py:90-115 + attend 117-180).  inputs_k and inputs_v must

@@ -113,6 +113,8 @@ SIGNATURES = {
     "pio_bn_relu_maxpool_tokens": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "pio_gemm_nt": (C.c_int, [P(Gemm), _vp]),
     "pio_softmax_rows": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _f, _vp, _vp, _vp, _vp, _i32, _vp]),
+    "pio_flash_attention": (C.c_int, [_i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i64, _i64, _i64,
+                                      _i64, _i64, _i64, _i64, _i64, _i32, _vp]),
     "pio_attention_workspace_bytes": (_sz, [P(Attention), _i32, _i32, _i32]),
     "pio_attention_fwd": (C.c_int, [P(Attention), P(Tensor3), P(Tensor3), P(Tensor3), _vp, _vp, _vp, _vp, _vp, _vp,
                                     _vp, _sz, _vp]),

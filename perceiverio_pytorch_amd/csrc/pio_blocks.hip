@@ -279,7 +279,9 @@ static int attention_core(const pio_attention_t &a, Pair xq, bool q_bcast, Pair 
         const int kvp = pad8(a.k_in);
         const bool kv_fold = kv_fold_enabled() && a.kq.w_hi && a.vo.w_hi && H == 1 && a.k_in == a.v_in && xk.hi == xv.hi &&
                              a.dk == a.k_in && a.dv == a.v_in && a.dkp == kvp && a.dvp == kvp && a.act_split != 1 &&
-                             !full_mask && !attention_bias && !probs_out && xattn_supported(kvp, kvp) &&
+                             // (no mask vectors: a row without an attendable key must come out as `final.bias` alone --
+                             //  transformer_primitives.py:168-175 -- but the folded bias Wo bv + bo assumes sum(P) = 1)
+                             !kv_mask && !q_mask && !full_mask && !attention_bias && !probs_out && xattn_supported(kvp, kvp) &&
                              a.kq.k == hdk && a.kq.n == kvp && a.vo.k == kvp && (int64_t)B * Tk >= 4 * (int64_t)Bq * Tq &&
                              !fold_in && !fold_out;
         if (kv_fold) {

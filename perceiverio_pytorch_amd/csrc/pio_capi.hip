@@ -193,4 +193,12 @@ int pio_softmax_rows(const float *S, int64_t lds, void *P, void *P_lo, int64_t l
                                (hipStream_t)stream);
 }
 
+int pio_flash_attention(int32_t dtype, int32_t dkp, int32_t dvp, int32_t dk, const void *Q, const void *K, const void *V,
+                        void *O, int32_t B, int32_t H, int32_t Tq, int32_t Tk, int64_t ldq, int64_t ldk, int64_t ldv,
+                        int64_t ldo, int64_t sQb, int64_t sKb, int64_t sVb, int64_t sOb, int32_t v_rowmajor, void *stream) {
+    if (dtype != PIO_DT_F16 && dtype != PIO_DT_BF16) return PIO_E_ARG;
+    return flash_attention_launch(dtype, dkp, dvp, dk, Q, K, V, O, B, H, Tq, Tk, ldq, ldk, ldv, ldo, sQb, sKb, sVb, sOb,
+                                  v_rowmajor != 0, (hipStream_t)stream);
+}
+
 }  // extern "C"

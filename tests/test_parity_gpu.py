@@ -1255,6 +1255,54 @@ def test_fused_cross_attention_real_projections_at_shipped_widths_vs_oracle(dev,
     assert rl2 <= tol and rmax <= tol, f"{what} [{policy}]: relL2={rl2:.3e} max/absmax={rmax:.3e} > {tol}"
 
 
+@pytest.mark.parametrize("policy", ["fp16", "fp16x2af"])
+@pytest.mark.parametrize("kv_in,Tq,Tk,B,bcast", [(322, 512, 3136, 3, True), (704, 200, 2500, 1, False),
+                                                 (512, 130, 4097, 2, False)])
+def test_kv_projection_fold_of_single_head_cross_attention(dev, kv_in, Tq, Tk, B, bcast, policy, monkeypatch):
+    """pio_attention_t.kq / vo: a single-head cross-attend over many keys computed as
+    softmax((Q Wk) LN(x)^T) LN(x) (Wo Wv)^T + (Wo bv + bo) -- no K / V projection GEMMs -- against the float64 oracle of
+    transformer_primitives.py:90-180, and against the un-folded path of the same policy.  With a key mask the fold must
+    step aside (a sample without an attendable key comes out as final.bias alone)."""
+    from perceiverio_pytorch_amd.transformer_primitives import Attention
+    q_in = 256
+    p = O.gen_attention("", q_in, kv_in, kv_in, kv_in, q_in, seed=kv_in + Tq)
+    rng = np.random.default_rng(Tk)
+    xq = rng.standard_normal((1 if bcast else B, Tq, q_in)).astype(np.float32)
+    xkv = rng.standard_normal((B, Tk, kv_in)).astype(np.float32)
+    m = Attention(q_in, kv_in, kv_in, num_heads=1, qk_out_channels=kv_in, v_out_channels=kv_in, output_channels=q_in)
+    m.load_state_dict(_sd(p, "cpu"))
+    m = m.to(dev).eval()
+    p64 = {k: a.astype(np.float64) for k, a in p.items()}
+    xq_full = np.broadcast_to(xq, (B, Tq, q_in))
+    ref = O.attention(p64, xq_full.astype(np.float64), xkv.astype(np.float64), xkv.astype(np.float64), 1, None)
+    xq_t = _t(xq, dev)
+    if bcast:
+        xq_t = torch.broadcast_to(xq_t, (B, Tq, q_in))
+    _policy(policy)
+    try:
+        y = _attention_vector_masks(m, xq_t, _t(xkv, dev), None, None, dev)
+        monkeypatch.setenv("PIO_KV_FOLD", "0")
+        y0 = _attention_vector_masks(m, xq_t, _t(xkv, dev), None, None, dev)
+        monkeypatch.delenv("PIO_KV_FOLD")
+        rl2, rmax = _assert_close(y, ref, TOL, what=f"K/V fold kv_in={kv_in} {policy}")
+        e0 = _errs(y0, ref)
+        print(f"kv_in={kv_in} Tq={Tq} Tk={Tk} {policy}: folded {rl2:.3e} / {rmax:.3e}, un-folded {e0[0]:.3e} / {e0[1]:.3e}")
+        assert not torch.equal(y, y0), "the fold did not engage"
+        # key mask with one sample fully masked: the un-folded path, bit for bit, and final.bias rows
+        km = rng.random((B, Tk)) > 0.3
+        km[:, 0] = True
+        km[B - 1, :] = False
+        ym = _attention_vector_masks(m, xq_t, _t(xkv, dev), km, None, dev)
+        monkeypatch.setenv("PIO_KV_FOLD", "0")
+        ym0 = _attention_vector_masks(m, xq_t, _t(xkv, dev), km, None, dev)
+        assert torch.equal(ym, ym0)
+        if policy == "fp16":
+            fb = m.final.bias.detach()
+            assert torch.equal(ym[B - 1], fb[None, :].expand_as(ym[B - 1]))
+    finally:
+        _policy("fp16x3")
+
+
 # ----------------------------------------------------------------------------------------------------
 # fp16 range: the LayerNorm-folded stack carries the residual stream as an fp16 pair
 # ----------------------------------------------------------------------------------------------------
