@@ -404,6 +404,20 @@ int pio_decoder_fwd(const pio_cross_attention_t *cross, const pio_linear_t *fina
                     const pio_tensor3_t *query, const pio_tensor3_t *latents, const uint8_t *query_mask,
                     float *out, void *workspace, size_t workspace_bytes, void *stream);
 
+/* The same with the PROJECTED QUERIES kept by the caller across calls (q16_hi == NULL: pio_decoder_fwd).  A decoder
+ * whose query array depends on parameters and constants only (the multimodal model's per-chunk Fourier queries,
+ * multimodal_perceiver.py:146-161) normalises and projects it once: q16_hi (and q16_lo when the attention descriptor
+ * carries split activations) are caller-owned device buffers of pio_decoder_qcache_bytes(cross, Bq, Q) bytes each, Bq = 1
+ * for a stride-0 (batch-invariant) query tensor, else B.  q16_valid == 0: LayerNorm_q + proj_q run and leave their result
+ * there; != 0: both are skipped and the buffers are read.  Only for cross->use_query_residual == 0 (PIO_E_ARG otherwise:
+ * the query rows themselves are needed then); the caller invalidates when the query array, layer_norm_q, proj_q or the
+ * precision policy change. */
+size_t pio_decoder_qcache_bytes(const pio_cross_attention_t *cross, int32_t Bq, int32_t Q);
+int pio_decoder_fwd_qcache(const pio_cross_attention_t *cross, const pio_linear_t *final_layer, int32_t final_out,
+                           const pio_tensor3_t *query, const pio_tensor3_t *latents, const uint8_t *query_mask,
+                           float *out, void *workspace, size_t workspace_bytes, void *stream, void *q16_hi,
+                           void *q16_lo, int32_t q16_valid);
+
 #ifdef __cplusplus
 }
 #endif

@@ -139,6 +139,9 @@ SIGNATURES = {
     "pio_decoder_workspace_bytes": (_sz, [P(CrossAttention), P(Linear), _i32, _i32, _i32]),
     "pio_decoder_fwd": (C.c_int, [P(CrossAttention), P(Linear), _i32, P(Tensor3), P(Tensor3), _vp, _vp, _vp, _sz,
                                   _vp]),
+    "pio_decoder_qcache_bytes": (_sz, [P(CrossAttention), _i32, _i32]),
+    "pio_decoder_fwd_qcache": (C.c_int, [P(CrossAttention), P(Linear), _i32, P(Tensor3), P(Tensor3), _vp, _vp, _vp, _sz,
+                                         _vp, _vp, _vp, _i32]),
 }
 
 _lib = None

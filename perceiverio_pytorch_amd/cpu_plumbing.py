@@ -31,7 +31,7 @@ def attention(m, xq, xk, xv, attention_mask=None, attention_bias=None, return_ma
     s = s * (1.0 / math.sqrt(q.shape[-1]))
     if attention_mask is not None:
         s = torch.where(attention_mask[:, None, :, :], s, torch.full_like(s, -1e30))
-    p = torch.softmax(s, dim=-1)
+    p = m.dropout(torch.softmax(s, dim=-1))             # (:158-160; identity in eval mode / p = 0)
     o = (p @ v).permute(0, 2, 1, 3).reshape(B, Tq, -1)
     if attention_mask is not None:
         live = attention_mask.any(dim=2)
@@ -41,13 +41,13 @@ def attention(m, xq, xk, xv, attention_mask=None, attention_bias=None, return_ma
 
 
 def mlp(m, x):
-    return m.fc2(F.gelu(m.fc1(x)))                      # exact (erf) GELU, :212-216
+    return m.dropout(m.fc2(F.gelu(m.fc1(x))))           # exact (erf) GELU, :212-216
 
 
 def self_attention(m, x, attention_mask=None, attention_bias=None, return_matrix=False):
     r = attention(m.attention, *(3 * (m.layer_norm1(x),)), attention_mask, attention_bias, return_matrix)
     probs, a = r if return_matrix else (None, r)
-    x = x + a
+    x = x + m.dropout(a)                                # (:289-290)
     x = x + mlp(m.mlp, m.layer_norm2(x))
     return (probs, x) if return_matrix else x
 
@@ -56,6 +56,7 @@ def cross_attention(m, xq, xkv, attention_mask=None, attention_bias=None, return
     kv = m.layer_norm_kv(xkv)
     r = attention(m.attention, m.layer_norm_q(xq), kv, kv, attention_mask, attention_bias, return_matrix)
     probs, a = r if return_matrix else (None, r)
+    a = m.dropout(a)                                    # (:390)
     x = xq + a if m._use_query_residual else a
     x = x + mlp(m.mlp, m.layer_norm2(x))
     return (probs, x) if return_matrix else x

@@ -229,13 +229,24 @@ static bool kv_fold_enabled() {
     return !e || atoi(e) != 0;
 }
 
+// Projected queries kept by the CALLER across calls (pio_decoder_fwd_qcache): a decoder whose query array depends on
+// parameters and constants only (the multimodal model's chunk queries) normalises and projects it once, not per call.
+struct QCache {
+    Pair pair;    // [Bq * Tq][H * dkp] 16-bit (+ lo half when the attention carries split activations)
+    bool valid;   // false: compute into `pair`; true: `pair` holds the projection -- skip LayerNorm_q and proj_q
+};
+
 static int attention_core(const pio_attention_t &a, Pair xq, bool q_bcast, Pair xk, Pair xv, int B, int Tq, int Tk,
                           const uint8_t *kv_mask, const uint8_t *q_mask, const uint8_t *full_mask,
                           const float *attention_bias, const Residual *res, float *out, float *probs_out,
                           AttnScratch &w, hipStream_t s, const LnFold *fold_in = nullptr,
-                          const LnFold *fold_out = nullptr, int64_t out_ld = 0) {
+                          const LnFold *fold_out = nullptr, int64_t out_ld = 0, const QCache *qc = nullptr) {
     if (!out_ld) out_ld = a.out;  // row pitch of `out` (>= a.out; an internal buffer may round it up: pitch4)
     PIO_TRY(check_attention(a));
+    if (qc) {
+        if (!qc->pair.hi || (a.act_split && !qc->pair.lo)) return PIO_E_ARG;
+        w.q16 = qc->pair;  // (the plan's own q16 carve stays unused)
+    }
     const int H = a.heads;
     const int64_t hdk = (int64_t)H * a.dkp, ldo = (int64_t)H * a.dvp, tkp = pad8(Tk), tkv = round_up(Tk, 32);
     const int Bq = q_bcast ? 1 : B;
@@ -250,7 +261,7 @@ static int attention_core(const pio_attention_t &a, Pair xq, bool q_bcast, Pair 
         //  LayerNorm fold, where the wide GEMM kernel, which honours pio_linear_t.lo_row0, is guaranteed)
         const pio_linear_t &qkv_used = (fold_in && fold_in->in_part) ? *fold_in->w : a.qkv;
         const bool qkv_lo_ok = !qkv_used.w_lo || (fold_in && fold_in->in_part && qkv_used.lo_row0 == 2 * hdk);
-        const bool fuse_qkv = a.qkv.w_hi && qkv_lo_ok && !a.act_split && !q_bcast && xq.hi == xk.hi &&
+        const bool fuse_qkv = !qc && a.qkv.w_hi && qkv_lo_ok && !a.act_split && !q_bcast && xq.hi == xk.hi &&
                               xk.hi == xv.hi && Tq == Tk && flash_supported(a.dkp, a.dvp) && a.qkv.n == ld3 &&
                               !kv_mask && !q_mask && !full_mask && !attention_bias && !probs_out &&
                               // (q16, k16, vt16 are consecutive carves: together they hold the [rows, ld3] matrix)
@@ -277,7 +288,7 @@ static int attention_core(const pio_attention_t &a, Pair xq, bool q_bcast, Pair 
     //     one 16-bit transpose of the inputs and the out projection over K = C.
     {
         const int kvp = pad8(a.k_in);
-        const bool kv_fold = kv_fold_enabled() && a.kq.w_hi && a.vo.w_hi && H == 1 && a.k_in == a.v_in && xk.hi == xv.hi &&
+        const bool kv_fold = !qc && kv_fold_enabled() && a.kq.w_hi && a.vo.w_hi && H == 1 && a.k_in == a.v_in && xk.hi == xv.hi &&
                              a.dk == a.k_in && a.dv == a.v_in && a.dkp == kvp && a.dvp == kvp && a.act_split != 1 &&
                              // (no mask vectors: a row without an attendable key must come out as `final.bias` alone --
                              //  transformer_primitives.py:168-175 -- but the folded bias Wo bv + bo assumes sum(P) = 1)
@@ -302,7 +313,7 @@ static int attention_core(const pio_attention_t &a, Pair xq, bool q_bcast, Pair 
     // 1/2: Q and K projections (transformer_primitives.py:93-94), head-padded columns.  When both read the same
     //      16-bit input (self-attention) they are ONE GEMM over the stacked [q rows | k rows] weight image: the
     //      q16 / k16 scratch regions are adjacent, the fused output uses them as one [rows, 2*H*dkp] matrix.
-    const bool fuse_qk = a.qk.w_hi && !a.act_split && !q_bcast && xq.hi == xk.hi && Tq == Tk &&
+    const bool fuse_qk = !qc && a.qk.w_hi && !a.act_split && !q_bcast && xq.hi == xk.hi && Tq == Tk &&
                          (char *)w.q16.hi + (size_t)B * Tq * hdk * 2 <= (char *)w.k16.hi && a.qk.n == 2 * hdk;
     const int64_t ldq = fuse_qk ? 2 * hdk : hdk;
     const void *k_hi = fuse_qk ? (const void *)((const char *)w.q16.hi + hdk * 2) : w.k16.hi;
@@ -310,7 +321,8 @@ static int attention_core(const pio_attention_t &a, Pair xq, bool q_bcast, Pair 
     if (fuse_qk) {
         PIO_TRY(linear_fwd(a.qk, a.dtype, xq, (int64_t)B * Tq, w.q16.hi, nullptr, false, 0, ldq, 0, nullptr, s));
     } else {
-        PIO_TRY(linear_fwd(a.q, a.dtype, xq, (int64_t)Bq * Tq, w.q16.hi, w.q16.lo, false, 0, ldq, 0, nullptr, s));
+        if (!(qc && qc->valid))
+            PIO_TRY(linear_fwd(a.q, a.dtype, xq, (int64_t)Bq * Tq, w.q16.hi, w.q16.lo, false, 0, ldq, 0, nullptr, s));
         PIO_TRY(linear_fwd(a.k, a.dtype, xk, (int64_t)B * Tk, w.k16.hi, w.k16.lo, false, 0, ldq, 0, nullptr, s));
     }
 
@@ -730,7 +742,8 @@ struct CrossPlan {
 static int cross_attention_run(const pio_cross_attention_t &ca, const pio_tensor3_t &iq, const pio_tensor3_t &ikv,
                                const uint8_t *kv_mask, const uint8_t *q_mask, const uint8_t *full_mask,
                                const float *attention_bias, float *out, float *probs_out, CrossPlan &p,
-                               hipStream_t s, const pio_tensor3_t *ikv_tail = nullptr, int64_t out_ld = 0) {
+                               hipStream_t s, const pio_tensor3_t *ikv_tail = nullptr, int64_t out_ld = 0,
+                               const QCache *qc = nullptr) {
     const int B = iq.B, Tq = iq.T, Tk = ikv.T;
     const int64_t rows = (int64_t)B * Tq;
     const int kv_c = ikv.C + (ikv_tail ? ikv_tail->C : 0);
@@ -743,11 +756,12 @@ static int cross_attention_run(const pio_cross_attention_t &ca, const pio_tensor
         PIO_TRY(cast_pair(ikv, &ca.ln_kv, p.kv16, padc(ikv.C), ca.attn.dtype, s));
     const pio_tensor3_t q1 = p.q_bcast ? first_batch(iq) : iq;
     const Pair qa = pair_if(p.q16, ca.attn.act_split);
-    PIO_TRY(cast_pair(q1, &ca.ln_q, qa, padc(iq.C), ca.attn.dtype, s));
+    if (qc && ca.use_query_residual) return PIO_E_ARG;  // (the query rows themselves are needed then)
+    if (!(qc && qc->valid)) PIO_TRY(cast_pair(q1, &ca.ln_q, qa, padc(iq.C), ca.attn.dtype, s));
     const Residual rq = residual_of(iq);
     PIO_TRY(attention_core(ca.attn, qa, p.q_bcast, p.kv16, p.kv16, B, Tq, Tk, kv_mask, q_mask, full_mask,
                            attention_bias, ca.use_query_residual ? &rq : nullptr, p.x1, probs_out, p.core, s, nullptr,
-                           nullptr, pitch4(iq.C)));
+                           nullptr, pitch4(iq.C), qc));
     // x + MLP(LN2(x))  (transformer_primitives.py:401)
     pio_tensor3_t t1 = {p.x1, (int64_t)Tq * pitch4(iq.C), pitch4(iq.C), B, Tq, iq.C};
     const Pair qm = pair_if(p.q16, ca.mlp.act_split);
@@ -968,7 +982,23 @@ size_t pio_decoder_workspace_bytes(const pio_cross_attention_t *cross, const pio
 int pio_decoder_fwd(const pio_cross_attention_t *cross, const pio_linear_t *final_layer, int32_t final_out,
                     const pio_tensor3_t *query, const pio_tensor3_t *latents, const uint8_t *query_mask, float *out,
                     void *workspace, size_t workspace_bytes, void *stream) {
+    return pio_decoder_fwd_qcache(cross, final_layer, final_out, query, latents, query_mask, out, workspace,
+                                  workspace_bytes, stream, nullptr, nullptr, 0);
+}
+
+size_t pio_decoder_qcache_bytes(const pio_cross_attention_t *cross, int32_t Bq, int32_t Q) {
+    if (!cross || Bq <= 0 || Q <= 0) return 0;
+    return (size_t)round_up((int64_t)Bq * Q * cross->attn.heads * cross->attn.dkp * 2, 256);
+}
+
+int pio_decoder_fwd_qcache(const pio_cross_attention_t *cross, const pio_linear_t *final_layer, int32_t final_out,
+                           const pio_tensor3_t *query, const pio_tensor3_t *latents, const uint8_t *query_mask,
+                           float *out, void *workspace, size_t workspace_bytes, void *stream, void *q16_hi,
+                           void *q16_lo, int32_t q16_valid) {
     if (!cross || !query || !latents || !out || !workspace) return PIO_E_ARG;
+    QCache qcache{{q16_hi, q16_lo}, q16_valid != 0};
+    const QCache *qc = q16_hi ? &qcache : nullptr;
+    if (qc && (((uintptr_t)q16_hi & 15) || ((uintptr_t)q16_lo & 15))) return PIO_E_ALIGN;
     hipStream_t s = (hipStream_t)stream;
     const int B = query->B, Q = query->T, N = latents->T;
     if (latents->B != B) return PIO_E_SHAPE;
@@ -979,7 +1009,7 @@ int pio_decoder_fwd(const pio_cross_attention_t *cross, const pio_linear_t *fina
     float *y = final_layer ? p.y : out;
     const int64_t y_ld = final_layer ? pitch4(query->C) : query->C;  // (y is internal when a final layer follows)
     PIO_TRY(cross_attention_run(*cross, *query, *latents, nullptr, query_mask, nullptr, nullptr, y, nullptr, p.cp,
-                                s, nullptr, y_ld));
+                                s, nullptr, y_ld, qc));
     if (!final_layer) return PIO_OK;
     // perceiver.py:178-179: final nn.Linear on every query row
     if (final_layer->k != padc(query->C)) return PIO_E_SHAPE;

@@ -27,12 +27,13 @@ constexpr int BM = 128, BN = 128, BK = 64;   // the default tile (launcher arith
 // TM x TN: 128 x 128 (four waves of 64 x 64) or 64 x 64 (four waves of 32 x 32: problems whose 128 x 128 tiling would
 // leave most of the 256 CUs idle -- a 2048-row latent stack at batch 1 has 64 such tiles per GEMM).
 // NS: operand stages in LDS.  2 = double buffer, the DMA of step t+1 against the MFMAs of step t (two workgroups per CU
-// hide each other's waits: the 128 x 128 tile on problems with many tiles).  6 (the 64 x 64 tile: problems of at most a
-// tile per CU, where nobody else covers a wait) = a RING: the pieces of step t+4 are issued at the top of step t, a
-// counted s_waitcnt vmcnt leaves four steps in flight across a raw s_barrier, every wave issues the same number of
-// pieces per step (steps past the end re-read valid memory into the slot the ring would use next: never read) -- with
-// the double buffer a 64 x 64 x 1024 tile spent ~1.9 k cycles per 64-deep step (the latency of one LDS-DMA round trip
-// under load) on 128 cycles of MFMAs.
+// hide each other's waits: the 128 x 128 tile on problems with many tiles).  4 (the 64 x 64 tile: problems of at most a
+// tile per CU, where nobody else covers a wait) = a RING: the pieces of step t+3 are issued at the top of step t, a
+// counted s_waitcnt vmcnt leaves two steps in flight across a raw s_barrier, every wave issues the same number of pieces
+// per step (steps past the end re-read valid memory into the slot the ring would use next: never read) -- with the
+// double buffer a 64 x 64 x 1024 tile spent ~1.9 k cycles per 64-deep step (the latency of one LDS-DMA round trip under
+// load) on 128 cycles of MFMAs.  (A six-stage ring -- four steps in flight, 96 KiB, one workgroup per CU -- measured no
+// better than four stages with two workgroups per CU: DESIGN_LOG R3.3.)
 template <int DT, int KIND, int TM, int TN, int NS>
 __global__ __launch_bounds__(256) void gemm_nt_128(const GemmParams p) {
     typedef typename Op<DT>::T T;

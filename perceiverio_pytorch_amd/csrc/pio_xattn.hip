@@ -513,7 +513,9 @@ struct XCfg {
     int dkl, dvs;
 };
 // the kernel instantiations, narrowest first
-constexpr XCfg kCfgs[] = {{32, 96}, {32, 160}, {128, 128}, {352, 352}, {352, 192}, {512, 512}, {512, 256}, {704, 256}};
+// (the sliced <352,192> / <512,256> instantiations of round 2 became unreachable when the single-pass <352,352> /
+// <512,512> ones were put in front of them in round 3 -- first match wins -- and are gone)
+constexpr XCfg kCfgs[] = {{32, 96}, {32, 160}, {128, 128}, {352, 352}, {512, 512}, {704, 256}};
 
 const XCfg *xattn_cfg(int dkp, int dvp) {
     for (const XCfg &c : kCfgs) {
@@ -601,10 +603,8 @@ int xattn_launch(int dtype, int dkp, int dvp, int dk_logical, const void *Q, con
         if (c->dkl == 32 && c->dvs == 96) PIO_XA(32, 96);
         else if (c->dkl == 32) PIO_XA(32, 160);
         else if (c->dkl == 128) PIO_XA(128, 128);
-        else if (c->dkl == 352 && c->dvs == 352) PIO_XA(352, 352);
-        else if (c->dkl == 352) PIO_XA(352, 192);
-        else if (c->dkl == 512 && c->dvs == 512) PIO_XA(512, 512);
-        else if (c->dkl == 512) PIO_XA(512, 256);
+        else if (c->dkl == 352) PIO_XA(352, 352);
+        else if (c->dkl == 512) PIO_XA(512, 512);
         else PIO_XA(704, 256);
 #undef PIO_XA
         if (nsplit > 1) {

@@ -359,30 +359,38 @@ class MultiModalPerceiver(nn.Module):
     # The decoder query array of an output chunk -- Fourier features of the chunk's index points, the learned label
     # query, the padding embeddings -- depends on no input, only on parameters and constants (every output query of
     # this model has concat_preprocessed_input=False): like the packed weight images it is built once per (parameter
-    # version, chunk group, batch, device) and kept (103 MB per group of 4 chunks at batch 1).  `cache_queries=False`
-    # rebuilds it on every call, as the reference does (multimodal_perceiver.py:146-161 -> perceiver.py:327-367).
+    # version, chunk group, device) and kept -- as ONE batch-invariant [1, Q, C] array (412 MB per group of 16 chunks,
+    # 3.3 GB for the 128 chunks of a forward, whatever the batch) that every sample reads through a stride-0 view: the
+    # decoder then also normalises / projects the queries once per call instead of once per sample.  The cache is bounded
+    # in BYTES (`query_cache_max_bytes`, default 8 GiB: two chunkings of a forward); `cache_queries=False` rebuilds the
+    # array on every call, as the reference does (multimodal_perceiver.py:146-161 -> perceiver.py:327-367).
     cache_queries = True
+    cache_projected_queries = True      # (needs cache_queries: the projection is kept beside the array it belongs to)
+    query_cache_max_bytes = 8 << 30
 
     def _chunk_queries(self, x, sizes, without_pos, points, chunk_key):
         P = self.perceiver
         if not self.cache_queries:
-            return P.decoder_query(x, sizes, without_pos, subsampled_points=points)
+            return P.decoder_query(x, sizes, without_pos, subsampled_points=points) + (None,)
         from . import runtime as R
         params = [p for q in P._output_queries.values() for p in q.parameters()] + list(P.padding_embeddings.parameters())
-        key = (chunk_key, x.shape[0], str(x.device), tuple(sorted(sizes.items())), R.param_key(*params)[:-1])
+        key = (chunk_key, str(x.device), tuple(sorted(sizes.items())), R.param_key(*params)[:-1])
         store = self.__dict__.setdefault("_query_cache", {})
         hit = store.get(key)
         if hit is None:
-            if len(store) > 256:
-                store.clear()
             with torch.inference_mode(False), torch.no_grad():
-                # (the queries read the batch size and the device from their input, nothing else: a stand-in of the
-                #  right length keeps the cached arrays ordinary -- not inference-mode -- tensors)
-                shape_only = torch.zeros((x.shape[0], x.shape[1], 1), device=x.device)
+                # (the queries read the batch size and the device from their input, nothing else: a ONE-sample stand-in of
+                #  the right length keeps the cached array batch-invariant and an ordinary -- not inference-mode -- tensor)
+                shape_only = torch.zeros((1, x.shape[1], 1), device=x.device)
                 q, qsizes = P.decoder_query(shape_only, sizes, None, subsampled_points=points)
-            hit = (q, qsizes)
+            nbytes = q.numel() * q.element_size()
+            held = sum(v[0].numel() * v[0].element_size() for v in store.values())
+            if held + nbytes > self.query_cache_max_bytes:
+                store.clear()
+            hit = (q, qsizes, {})          # ({}: the decoder's cache of the PROJECTED queries of this array)
             store[key] = hit
-        return hit
+        q, qsizes, qc = hit
+        return torch.broadcast_to(q, (x.shape[0],) + tuple(q.shape[1:])), qsizes, qc
 
     def _forward(self, images, audio, n_chunks):
         b, t, c, h, w = images.shape
@@ -410,10 +418,13 @@ class MultiModalPerceiver(nn.Module):
                     with precision(P.encoder_policy):
                         cached = (x, sizes, without_pos, P._encoder(x, P._encoder.latents(x)))
                 x, sizes, without_pos, latents = cached
-                query, qsizes = self._chunk_queries(x, sizes, without_pos, points, (k, g, n_chunks))
+                query, qsizes, qc = self._chunk_queries(x, sizes, without_pos, points, (k, g, n_chunks))
                 from .perceiver import restructure
                 with precision(P.decoder_policy):
-                    per_mod = restructure(qsizes, P._decoder(query, latents))
+                    # (qc: LayerNorm_q + proj_q of a cached -- parameter-only -- query array run once, not per forward:
+                    #  206 MB of projected queries per group of 16 chunks at the default policy)
+                    per_mod = restructure(qsizes, P._decoder(query, latents, q_cache=qc if self.cache_projected_queries
+                                                             else None))
                     out = {m: post(per_mod[m], pos=None, modality_sizes=None)
                            for m, post in P._output_postprocessors.items()}
             rec["image"].append(out["image"])

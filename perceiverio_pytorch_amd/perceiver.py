@@ -98,7 +98,7 @@ class PerceiverEncoder(nn.Module):
         guard = R.range_check() and Lyr > 0 and not self._range_fallback
         flag = None
         if guard:
-            flag = R.range_flag(dev)
+            flag = R.range_flag(dev, self)        # this encoder's own word (two models on a device do not share one)
             flag.zero_()
         # the descriptor array handed to the library: rebuilt only when a descriptor or the guard word changes (the
         # cached descriptor objects are replaced whenever their parameters / the policy change)
@@ -229,7 +229,12 @@ class PerceiverDecoder(nn.Module):
             self._final_cache = (key, R.PackedLinear(self.final_layer.weight, self.final_layer.bias, 1, 1, dtype, two))
         return self._final_cache[1]
 
-    def forward(self, query, latents, *, query_mask=None):
+    def forward(self, query, latents, *, query_mask=None, q_cache=None):
+        """Reference signature (perceiver.py:166) plus `q_cache`: a dict the CALLER keeps per query array whose content
+        depends on parameters and constants only (MultiModalPerceiver's per-chunk queries).  The decoder leaves the
+        normalised + projected queries there on the first call and skips LayerNorm_q / proj_q afterwards
+        (pio_decoder_fwd_qcache); it revalidates the entry against its own parameters and the precision policy.  Only
+        without the query residual."""
         if R.cpu_plumbing(query, "PerceiverDecoder.forward"):
             from . import cpu_plumbing as CP
             return CP.decoder(self, query, latents, query_mask)
@@ -246,9 +251,35 @@ class PerceiverDecoder(nn.Module):
         out = torch.empty((B, Q, out_ch), dtype=torch.float32, device=dev)
         fin_ptr = C.byref(fin.desc) if fin is not None else None
         ws = R.workspace(dev, lib.pio_decoder_workspace_bytes(cross, fin_ptr, B, Q, N))
+        qhi = qlo = None
+        valid = 0
+        if q_cache is not None and not self._use_query_residual:
+            ca = self.decoding_cross_attn
+            Bq = 1 if (q.stride(0) == 0 and B > 1) else B
+            try:
+                qver = q._version
+            except RuntimeError:                 # (inference tensors carry no version counter)
+                qver = -1
+            key = (R.param_key(ca.layer_norm_q.weight, ca.layer_norm_q.bias, ca.attention.proj_q.weight,
+                               ca.attention.proj_q.bias), Bq, Q, q.data_ptr(), qver, int(cross.attn.act_split))
+            fresh = q_cache.get("key") != key
+            # (during stream capture a cache is only READ: nothing is allocated or validated inside a graph)
+            if not (R.capturing(dev) and (fresh or not q_cache.get("valid"))):
+                if fresh:
+                    nb = lib.pio_decoder_qcache_bytes(cross, Bq, Q)
+                    with torch.inference_mode(False):
+                        q_cache["hi"] = torch.empty(nb, dtype=torch.uint8, device=dev)
+                        q_cache["lo"] = torch.empty(nb, dtype=torch.uint8, device=dev) if cross.attn.act_split else None
+                    q_cache["key"], q_cache["valid"] = key, False
+                qhi = q_cache["hi"].data_ptr()
+                qlo = q_cache["lo"].data_ptr() if q_cache["lo"] is not None else None
+                valid = 1 if q_cache["valid"] else 0
         with R.on_device(dev):
-            L.check(lib.pio_decoder_fwd(cross, fin_ptr, out_ch, R.tensor3(q), R.tensor3(z), qm_ptr, out.data_ptr(),
-                                        ws.data_ptr(), ws.numel(), R.stream_ptr(dev)), "pio_decoder_fwd")
+            L.check(lib.pio_decoder_fwd_qcache(cross, fin_ptr, out_ch, R.tensor3(q), R.tensor3(z), qm_ptr, out.data_ptr(),
+                                               ws.data_ptr(), ws.numel(), R.stream_ptr(dev), qhi, qlo, valid),
+                    "pio_decoder_fwd")
+        if qhi is not None:
+            q_cache["valid"] = True
         return R.forward_only(out, query, latents, *self.parameters())
 
 

@@ -108,7 +108,7 @@ def policy_dtype(name: Optional[str] = None) -> Tuple[int, bool, bool]:
 # the word stays in `last_range_flag()` for the owner of the graph to look at after a replay.
 # ------------------------------------------------------------------------------------------------
 _range_check = os.environ.get("PIO_RANGE_CHECK", "1") != "0"
-_range_flags: Dict[int, torch.Tensor] = {}
+_range_flags: Dict[tuple, torch.Tensor] = {}
 _range_deferred: Optional[list] = None      # not None: PerceiverIO.forward collects the encoder's pending checks
 
 
@@ -121,20 +121,27 @@ def set_range_check(on: bool) -> None:
     _range_check = bool(on)
 
 
-def range_flag(device: torch.device) -> torch.Tensor:
-    """The device word the folded stack reports into (one per device, int32[1])."""
+def range_flag(device: torch.device, owner=None) -> torch.Tensor:
+    """The device word a folded stack reports into (int32[1]): ONE PER OWNER (a PerceiverEncoder instance) and device, so
+    that two models running on one device never clear or read each other's word; `last_range_flag(device)` is the word of
+    the forward that ran last there (what the owner of a captured graph reads after a replay)."""
     idx = device.index if device.index is not None else torch.cuda.current_device()
-    t = _range_flags.get(idx)
+    key = (idx, id(owner) if owner is not None else 0)
+    t = _range_flags.get(key)
     if t is None:
         with torch.inference_mode(False):     # (a normal tensor: zeroed in place from inside and outside inference mode)
             t = torch.zeros(1, dtype=torch.int32, device=device)
-        _range_flags[idx] = t
+        _range_flags[key] = t
+        if owner is not None:
+            import weakref
+            weakref.finalize(owner, _range_flags.pop, key, None)
+    _range_flags[(idx, "last")] = t
     return t
 
 
 def last_range_flag(device: Optional[torch.device] = None) -> Optional[torch.Tensor]:
     idx = (device.index if device is not None and device.index is not None else torch.cuda.current_device())
-    return _range_flags.get(idx)
+    return _range_flags.get((idx, "last"))
 
 
 class defer_range_checks:

@@ -256,6 +256,14 @@ def test_model_outputs_match_reference(name, policy):
             _close(out["image"], g["out_image"], name + " image", tol)
             _close(out["audio"], g["out_audio"], name + " audio", tol)
             _close(out["label"], g["out_label"], name + " label", tol)
+            # the decoder's cache of the projected chunk queries (pio_decoder_fwd_qcache): first call fills it, second
+            # reads it, without it the same arithmetic runs per call -- all three bit-identical
+            again = model(ins[0], ins[1], n_chunks=2)
+            model.cache_projected_queries = False
+            plain = model(ins[0], ins[1], n_chunks=2)
+            model.cache_projected_queries = True
+            for mname in ("image", "audio", "label"):
+                assert torch.equal(out[mname], again[mname]) and torch.equal(out[mname], plain[mname]), mname
             model.decode_chunks_per_call = 1     # one decoder call per chunk ...
             out1 = model(ins[0], ins[1], n_chunks=2)
             model.encode_once = False            # ... and the reference's recompute-per-chunk loop give the same result
