@@ -64,7 +64,7 @@ CONFIGS = {
                      # parameter statistics (8.3e-4 / 1.72e-3); the default splits the weights of the encoder's cross-attend and
                      # both operands of the decoder (weights applied once, 1.2 of 16 ms) around the single-sweep fp16sd stack:
                      # worst of eight goldens 5.6e-4 / 5.8e-4 (models.py DEFAULT_POLICY, tools/r4_policy_table.py)
-                     batch=32, policy="fp16x2w/fp16sd/fp16x3f",
+                     batch=32, policy="fp16x2w/fp16sd/fp16x2af",
                      gflop=381.65, scaling="weak",
                      metric="samples/sec PerceiverIO fwd (ImageNet-224, 512x1024 latents, 8 blocks x 6 self-attends)",
                      workload="imagenet224 ClassificationPerceiver (conv+Fourier prep -> encoder 3136x322->512x1024, "

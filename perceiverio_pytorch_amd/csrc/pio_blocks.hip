@@ -292,7 +292,8 @@ static int attention_core(const pio_attention_t &a, Pair xq, bool q_bcast, Pair 
                              a.dk == a.k_in && a.dv == a.v_in && a.dkp == kvp && a.dvp == kvp && a.act_split != 1 &&
                              // (no mask vectors: a row without an attendable key must come out as `final.bias` alone --
                              //  transformer_primitives.py:168-175 -- but the folded bias Wo bv + bo assumes sum(P) = 1)
-                             !kv_mask && !q_mask && !full_mask && !attention_bias && !probs_out && xattn_supported(kvp, kvp) &&
+                             !kv_mask && !q_mask && !full_mask && !attention_bias && !probs_out &&
+                             (xattn_supported(kvp, kvp) || xtall_supported(kvp, kvp, Tk)) &&
                              a.kq.k == hdk && a.kq.n == kvp && a.vo.k == kvp && (int64_t)B * Tk >= 4 * (int64_t)Bq * Tq &&
                              !fold_in && !fold_out;
         if (kv_fold) {
@@ -302,10 +303,16 @@ static int attention_core(const pio_attention_t &a, Pair xq, bool q_bcast, Pair 
             PIO_TRY(linear_fwd(a.kq, a.dtype, w.q16, (int64_t)Bq * Tq, w.k16.hi, w.k16.lo, false, 0, kvp, 0, nullptr, s));
             const int64_t ldx = padc(a.k_in);      // row pitch of the LayerNorm'd inputs
             PIO_TRY(transpose16_launch(xk.hi, ldx, B, Tk, kvp, w.vt16.hi, tkv, s));
-            PIO_TRY(xattn_launch(a.dtype, kvp, kvp, a.dk, w.k16.hi, xk.hi, w.vt16.hi, w.o16.hi,
-                                 single_core ? w.o16.lo : nullptr, B, H, Tq, Tk, kvp, ldx, tkv, kvp,
-                                 q_bcast ? 0 : (int64_t)Tq * kvp, (int64_t)Tk * ldx, (int64_t)kvp * tkv, (int64_t)Tq * kvp,
-                                 kv_mask, q_mask, w.xpart, s));
+            if (xattn_supported(kvp, kvp))
+                PIO_TRY(xattn_launch(a.dtype, kvp, kvp, a.dk, w.k16.hi, xk.hi, w.vt16.hi, w.o16.hi,
+                                     single_core ? w.o16.lo : nullptr, B, H, Tq, Tk, kvp, ldx, tkv, kvp,
+                                     q_bcast ? 0 : (int64_t)Tq * kvp, (int64_t)Tk * ldx, (int64_t)kvp * tkv,
+                                     (int64_t)Tq * kvp, kv_mask, q_mask, w.xpart, s));
+            else  // (a head wider than the tiled kernel covers over <= 512 keys: the ImageNet decoder)
+                PIO_TRY(xtall_launch(a.dtype, kvp, kvp, a.dk, w.k16.hi, xk.hi, w.vt16.hi, w.o16.hi,
+                                     single_core ? w.o16.lo : nullptr, B, H, Tq, Tk, kvp, ldx, tkv, kvp,
+                                     q_bcast ? 0 : (int64_t)Tq * kvp, (int64_t)Tk * ldx, (int64_t)kvp * tkv,
+                                     (int64_t)Tq * kvp, kv_mask, q_mask, w.xpart, s));
             return linear_fwd(a.vo, a.dtype, w.o16, (int64_t)B * Tq, out, nullptr, true, a.out, out_ld, 0, res, s);
         }
     }

@@ -12,6 +12,7 @@ Reference lines (under /root/reference/perceiver_io/transformer_primitives.py):
 from __future__ import annotations
 
 import math
+import os
 from typing import Optional
 
 import torch
@@ -160,8 +161,13 @@ class Attention(_HipModule):
         # 9.7e-4 / 1.06e-3 to 5.4e-4 / 5.6e-4, the flow forward from 5.66 to 5.42 ms.  Under the split-weight policies the
         # un-folded projections (K rounded AFTER an exact product) stay: 5.5e-4 / 5.8e-4 against 6.0e-4 / 8.4e-4 folded --
         # Q Wk concentrates on the outlier columns of a heavy-tailed Wk and multiplies the rounding of x there.
+        # The library also takes it for the ImageNet DECODER (1024-wide head over 512 latents, batch-invariant queries:
+        # xattn_tall_kernel reads the LayerNorm'd latents) -- under "fp16x2af" its K / V projections (2 x 34 GFLOP x 2
+        # sweeps at B = 32) are gone: 6.5e-4 / 7.0e-4 -> 6.05e-4 / 5.6e-4 on the eight goldens, 16.49 -> 16.26 ms against
+        # the split-operand ("x3f") decoder.
         kin = self.proj_k.in_features
-        if H == 1 and kin == self.proj_v.in_features and dk == kin and dv == kin and wlevel == 0:
+        if H == 1 and kin == self.proj_v.in_features and dk == kin and dv == kin and (
+                wlevel == 0 or os.environ.get("PIO_KV_FOLD_ANY") == "1"):   # (env: A/B experiments, tools/)
             with torch.no_grad():
                 Wk, Wv, Wo = wt(self.proj_k).double(), wt(self.proj_v).double(), wt(self.final).double()
                 bv = self.proj_v.bias.double() if self.proj_v.bias is not None else torch.zeros(kin, device=Wv.device)

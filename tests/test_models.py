@@ -26,8 +26,8 @@ def spec_of(g):
 
 def test_default_policies_are_the_validated_ones():
     from perceiverio_pytorch_amd import models as M
-    assert M.ClassificationPerceiver().precision_policy == "fp16x2w/fp16sd/fp16x3f"
-    assert M.DEFAULT_POLICY == {"ClassificationPerceiver": "fp16x2w/fp16sd/fp16x3f",
+    assert M.ClassificationPerceiver().precision_policy == "fp16x2w/fp16sd/fp16x2af"
+    assert M.DEFAULT_POLICY == {"ClassificationPerceiver": "fp16x2w/fp16sd/fp16x2af",
                                 "LanguagePerceiver": "fp16x2w/fp16x2o/fp16x3f",
                                 "FlowPerceiver": "fp16/fp16x2af", "MultiModalPerceiver": "fp16x2w/fp16x3f"}
     assert M.split_policy("fp16x2w/fp16x3") == ("fp16x2w", "fp16x3") and M.split_policy("fp16") == ("fp16", "fp16")
@@ -84,11 +84,12 @@ B4_CASES = sorted(n for n in MODEL_CASES if n.startswith("model_classify_b4_"))
 # (tools/r4_policy_table.py); the others are held to the six initialiser-like goldens only: on "trained2" (heavy-tailed
 # weight rows, natural-image inputs) single-sweep cross-attends exceed the bar -- fp16sd 8.3e-4 / 1.72e-3, fp16sd/fp16x3f
 # 6.7e-4 / 1.23e-3, fp16x2s 7.5e-4 / 1.0e-3 -- which is why they are not defaults
-ROBUST_POLICIES = ("fp16x2w/fp16sd/fp16x3f", "fp16x3f/fp16sd/fp16x3f", "fp16x2w", "fp16x3")
+ROBUST_POLICIES = ("fp16x2w/fp16sd/fp16x2af", "fp16x2w/fp16sd/fp16x3f", "fp16x3f/fp16sd/fp16x3f", "fp16x2w", "fp16x3")
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("policy", ["fp16", "fp16sd", "fp16sd/fp16x3f", "fp16x2w/fp16sd/fp16x3f", "fp16x3f/fp16sd/fp16x3f",
+@pytest.mark.parametrize("policy", ["fp16", "fp16sd", "fp16sd/fp16x3f", "fp16x2w/fp16sd/fp16x2af", "fp16x2w/fp16sd/fp16x3f",
+                                    "fp16x3f/fp16sd/fp16x3f",
                                     "fp16x2s", "fp16x2w", "fp16x3"])
 @pytest.mark.parametrize("name", B4_CASES)
 def test_benchmarked_path_matches_reference(name, policy):
@@ -297,7 +298,10 @@ def test_classifier_row0_only_decoder_matches_full_decoder(policy):
         y_row0 = model(x)
     assert y_row0.shape == y_full.shape == (2, 1000)
     _close(y_row0, g["out"], f"row-0 decoder vs golden [{policy}]", TOL if policy != "fp16x3" else 1e-4)
-    _close(y_row0, y_full.cpu().numpy(), f"row-0 decoder vs all rows [{policy}]", 2e-4 if policy != "fp16x3" else 1e-5)
+    # (under the single-weight policy the one-row decode -- 1024 keys against 1 query row per sample -- takes the K / V
+    #  projection fold and the 1000-row decode of B = 2 does not: two roundings of the same result, each held to the golden)
+    _close(y_row0, y_full.cpu().numpy(), f"row-0 decoder vs all rows [{policy}]",
+           {"fp16x3": 1e-5, "fp16": TOL}.get(policy, 2e-4))
 
 
 @pytest.mark.gpu

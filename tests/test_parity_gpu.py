@@ -1257,7 +1257,8 @@ def test_fused_cross_attention_real_projections_at_shipped_widths_vs_oracle(dev,
 
 @pytest.mark.parametrize("policy", ["fp16", "fp16x2af"])
 @pytest.mark.parametrize("kv_in,Tq,Tk,B,bcast", [(322, 512, 3136, 3, True), (704, 200, 2500, 1, False),
-                                                 (512, 130, 4097, 2, False)])
+                                                 (512, 130, 4097, 2, False),
+                                                 (1024, 1000, 512, 8, True)])   # the ImageNet decoder's shape: xattn_tall
 def test_kv_projection_fold_of_single_head_cross_attention(dev, kv_in, Tq, Tk, B, bcast, policy, monkeypatch):
     """pio_attention_t.kq / vo: a single-head cross-attend over many keys computed as
     softmax((Q Wk) LN(x)^T) LN(x) (Wo Wv)^T + (Wo bv + bo) -- no K / V projection GEMMs -- against the float64 oracle of
