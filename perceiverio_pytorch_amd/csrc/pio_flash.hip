@@ -56,7 +56,12 @@ __device__ __forceinline__ int vrow_swz(int r) {
     else return 0;
 }
 
-template <int DT, int DK, int DV, bool VROW, int NW>
+// KS = 2 (NW = 8; launcher: Tk % 128 == 0 and at most one 128-row workgroup per CU): the KEY axis is split over two wave
+// groups of the workgroup -- wave w owns query block w % 4 and key half w / 4 -- which run their halves side by side
+// (two waves per SIMD: one wave's dependent MFMA -> exp2 -> MFMA chain covers the other's) and merge (m, l, O) through
+// LDS at the end.  For the shapes that offer only one 4-wave workgroup per CU: the flow stack (16 heads x 2048 latents:
+// 256 workgroups of ~1 900 cycles per 64-key tile against 256 cycles of MFMAs), small ImageNet batches.
+template <int DT, int DK, int DV, bool VROW, int NW, int KS = 1>
 __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void flash_attn_kernel(const FlashParams p) {
     typedef typename Op<DT>::T T;
     typedef typename Op<DT>::V8 V8;
@@ -73,8 +78,12 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void flash_attn_kernel(co
     constexpr int NDT = DV / 32;                 // 32-row O^T tiles
     constexpr int NQS = DK / 16;                 // k-steps of the Q.K product
     constexpr int OROW = DV * 2 + 16;            // epilogue staging: bytes per output row (+16: rows spread over banks)
-    constexpr int RING = 2 * (K_TILE + V_TILE), OSTG = NW * 32 * OROW;
-    __shared__ __attribute__((aligned(16))) char smem[RING > OSTG ? RING : OSTG];
+    static_assert(KS == 1 || (KS == 2 && NW == 8), "key split: two groups of four waves");
+    constexpr int NWQ = NW / KS;                 // waves along the query axis
+    constexpr int MRG = KS == 2 ? NWQ * 64 * (NDT * 16 + 2) * 4 : 0;   // merge area: (O^T, m, l) of the second key half
+    constexpr int RING = 2 * KS * (K_TILE + V_TILE), OSTG = NW * 32 * OROW;
+    constexpr int SM0 = RING > OSTG ? RING : OSTG;
+    __shared__ __attribute__((aligned(16))) char smem[SM0 > MRG ? SM0 : MRG];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -87,7 +96,8 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void flash_attn_kernel(co
     if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
     const int qt = bid % p.nqt, bh = bid / p.nqt;
     const int b = bh / p.H, h = bh % p.H;
-    const int q0 = qt * (NW * 32) + wave * 32;
+    const int qb = KS == 1 ? wave : wave % NWQ, kh = KS == 1 ? 0 : wave / NWQ;   // query block, key half of this wave
+    const int q0 = qt * (NWQ * 32) + qb * 32;
 
     const T *Qg = (const T *)p.Q + b * p.sQb + (int64_t)h * DK;
     const T *Kg = (const T *)p.K + b * p.sKb + (int64_t)h * DK;
@@ -96,14 +106,16 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void flash_attn_kernel(co
 
     V8 qf[NQS];  // Q fragments (B operand), loaded behind the first tile's request: the two latencies overlap
 
-    const int ntiles = (p.Tk + KT - 1) / KT;
+    const int ntiles_all = (p.Tk + KT - 1) / KT;
+    const int ntiles = ntiles_all / KS;          // (KS == 2: an even tile count -- launcher) tiles of this key half
+    const int tile0 = kh * ntiles;               // its first tile
 
-    auto stage = [&](int kt, int buf) {
-        char *kb = smem + buf * (K_TILE + V_TILE);
+    auto stage = [&](int kt, int buf) {          // tile kt of THIS key half, staged by the half's NWQ waves
+        char *kb = smem + (buf * KS + kh) * (K_TILE + V_TILE);
         char *vb = kb + K_TILE;
-        const int k0 = kt * KT;
+        const int k0 = (tile0 + kt) * KT;
         // K tile: piece = 64 chunks = 64/KCPR rows
-        for (int pc = wave; pc < K_PIECES; pc += NW) {
+        for (int pc = qb; pc < K_PIECES; pc += NWQ) {
             const int row = pc * (64 / KCPR) + lane / KCPR;
             const int slot = lane % KCPR;
             const int c = slot ^ ((row / KRPB) & (KCPR - 1));
@@ -116,7 +128,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void flash_attn_kernel(co
         if constexpr (VROW) {
             // row-major V tile [64 keys][DV]: DV / 8 chunks per row, a 1-KiB piece = 64 consecutive chunks
             constexpr int VCPR = DV / 8;
-            for (int pc = wave; pc < V_PIECES; pc += NW) {
+            for (int pc = qb; pc < V_PIECES; pc += NWQ) {
                 const int idx = pc * 64 + lane;
                 const int row = idx / VCPR;
                 const int slot = idx - row * VCPR;
@@ -130,7 +142,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void flash_attn_kernel(co
             }
         } else
         // V^T tile: rows = dv (128-byte rows, 8 chunks), piece = 8 rows
-        for (int pc = wave; pc < V_PIECES; pc += NW) {
+        for (int pc = qb; pc < V_PIECES; pc += NWQ) {
             const int row = pc * 8 + (lane >> 3);
             const int slot = lane & 7;
             const int c = slot ^ ((row >> 1) & 7);
@@ -169,7 +181,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void flash_attn_kernel(co
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (kt + 1 < ntiles) stage(kt + 1, (kt + 1) & 1);
-        const char *kb = smem + (kt & 1) * (K_TILE + V_TILE);
+        const char *kb = smem + ((kt & 1) * KS + kh) * (K_TILE + V_TILE);
         const char *vb = kb + K_TILE;
 
         // ---- S^T = K Q^T for the two 32-key halves
@@ -186,7 +198,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void flash_attn_kernel(co
             }
         }
         // ---- scale to base 2, mask keys past Tk (last tile only), tile max
-        const bool tail = (kt == ntiles - 1) && (p.Tk % KT != 0);
+        const bool tail = KS == 1 && (kt == ntiles - 1) && (p.Tk % KT != 0);
         // The max is taken on the RAW scores (scale > 0 commutes with max); the scale and the max subtraction are
         // then one FMA per element:  p = exp2(s * c - m * c).
         float mx = -INFINITY;
@@ -195,7 +207,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void flash_attn_kernel(co
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    const int key = kt * KT + 32 * t + (i & 3) + 8 * (i >> 2) + 4 * hh;
+                    const int key = (tile0 + kt) * KT + 32 * t + (i & 3) + 8 * (i >> 2) + 4 * hh;
                     if (key >= p.Tk) sacc[t][i] = -INFINITY;
                 }
         }
@@ -277,6 +289,32 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void flash_attn_kernel(co
         }
     }
 
+    if constexpr (KS == 2) {
+        // ---- merge the two key halves: the second half parks (O^T, m, l) in LDS (the ring is free behind the barrier),
+        // the first half folds it in: m = max(m0, m1), O = O0 2^(m0 - m) + O1 2^(m1 - m), l likewise (per-lane partials)
+        __syncthreads();
+        float *mg = (float *)smem + (size_t)(qb * 64 + lane) * (NDT * 16 + 2);
+        if (kh == 1) {
+#pragma unroll
+            for (int d = 0; d < NDT; ++d)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) mg[d * 16 + j] = oacc[d][j];
+            mg[NDT * 16] = m_run;
+            mg[NDT * 16 + 1] = l_run;
+        }
+        __syncthreads();
+        if (kh == 0) {
+            const float m1 = mg[NDT * 16], l1 = mg[NDT * 16 + 1];
+            const float m = fmaxf(m_run, m1);
+            const float a0 = __builtin_amdgcn_exp2f(m_run - m), a1 = __builtin_amdgcn_exp2f(m1 - m);
+#pragma unroll
+            for (int d = 0; d < NDT; ++d)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) oacc[d][j] = oacc[d][j] * a0 + mg[d * 16 + j] * a1;
+            l_run = l_run * a0 + l1 * a1;
+            m_run = m;
+        }
+    }
     // ---- epilogue: combine the two half-column sums, normalise, store O[q][h*DV + d]
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
@@ -285,7 +323,8 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void flash_attn_kernel(co
         // stores 16 contiguous bytes, DV / 8 lanes one row -- instead of 8-byte pieces of 32 different rows per
         // instruction (stamps of the pipelined kernel below: that form spent 8.7 k cycles per workgroup issuing stores).
         __syncthreads();
-        char *const ost = smem + wave * (32 * OROW);
+        if (kh != 0) return;                     // (KS == 2: the first key half's waves hold the merged result)
+        char *const ost = smem + qb * (32 * OROW);
         char *const orow = ost + r32 * OROW;
 #pragma unroll
         for (int d = 0; d < NDT; ++d)
@@ -308,7 +347,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void flash_attn_kernel(co
         return;
     }
     const int q = q0 + r32;
-    if (q < p.Tq) {
+    if (q < p.Tq && kh == 0) {
         T *orow = (T *)p.O + b * p.sOb + (int64_t)q * p.ldo + (int64_t)h * DV;
 #pragma unroll
         for (int d = 0; d < NDT; ++d)
@@ -366,7 +405,8 @@ int flash_attention_launch(int dtype, int dkp, int dvp, int dk_logical, const vo
     const int o_rows16 = (ldo % 8 == 0 && sOb % 8 == 0 && ((uintptr_t)O & 15) == 0) ? 1 : 0;
     FlashParams p{Q, K, VT, O, Tq, Tk, H, nqt, ldq, ldk, ldvt, ldo, sQb, sKb, sVb, sOb,
                   1.4426950408889634f / sqrtf((float)dk_logical), o_rows16};
-    dim3 grid((unsigned)(nqt * B * H), 1, 1), block(wide ? 512 : 256, 1, 1);
+    dim3 grid((unsigned)(nqt * B * H), 1, 1);
+    dim3 block(wide ? 512 : 256, 1, 1);
     ProfScope prof(PROF_FLASH, 2.0 * B * H * (double)Tq * Tk * (dkp + dvp),
                    2.0 * B * H * ((double)Tq * (dkp + dvp) + (double)Tk * (dkp + dvp)), s);
 #define PIO_FLASH(DTV, DKV, DVV) hipLaunchKernelGGL((flash_attn_kernel<DTV, DKV, DVV, false, 4>), grid, block, 0, s, p)
@@ -400,7 +440,27 @@ int flash_attention_launch(int dtype, int dkp, int dvp, int dk_logical, const vo
         else hipLaunchKernelGGL((flash_attn_stag_kernel<PIO_DT_BF16>), grid, block, 0, s, p);
     } else
 #endif
-    if (v_rowmajor) {
+    // key split over two wave groups (KS = 2): when the launch offers at most one 128-row workgroup per CU
+    static const bool ksplit_on = [] {
+        const char *e = getenv("PIO_FLASH_KSPLIT");
+        return !e || atoi(e) != 0;
+    }();
+    const bool ksplit = ksplit_on && v_rowmajor && !wide && Tk >= 256 && (Tk % 128) == 0 &&
+                        (int64_t)B * H * nqt <= cu_budget();
+    if (ksplit) {
+        block = dim3(512, 1, 1);
+#define PIO_FLASH_KS(DKV, DVV)                                                                                        \
+    do {                                                                                                              \
+        if (dtype == PIO_DT_F16)                                                                                      \
+            hipLaunchKernelGGL((flash_attn_kernel<PIO_DT_F16, DKV, DVV, true, 8, 2>), grid, block, 0, s, p);          \
+        else hipLaunchKernelGGL((flash_attn_kernel<PIO_DT_BF16, DKV, DVV, true, 8, 2>), grid, block, 0, s, p);        \
+    } while (0)
+        if (dkp == 128 && dvp == 128) PIO_FLASH_KS(128, 128);
+        else if (dkp == 64 && dvp == 64) PIO_FLASH_KS(64, 64);
+        else if (dkp == 32 && dvp == 32) PIO_FLASH_KS(32, 32);
+        else PIO_FLASH_KS(32, 160);
+#undef PIO_FLASH_KS
+    } else if (v_rowmajor) {
 #define PIO_FLASH_ROW(DKV, DVV)                                                                                        \
     do {                                                                                                               \
         if (wide) {                                                                                                    \
