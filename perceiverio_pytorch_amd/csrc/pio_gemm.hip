@@ -561,10 +561,18 @@ int gemm_nt_launch(const pio_gemm_t &g, hipStream_t s) {
     // stack of the flow model at B = 1 has 64 tiles of 128 x 128 per GEMM, 256 of 64 x 64); override 64 forces them
     const int64_t tiles128 = (int64_t)tiles_m * p.tiles_n * g.batch;
     const bool small = gemm_kernel_choice() == 64 || (gemm_kernel_choice() == 0 && tiles128 < 192);
-    gemm_log(small ? "t64" : "t128", g, p);
+    // ... and 32 x 64 tiles when even the 64 x 64 tiling leaves a third of the CUs without one (ImageNet B = 1: the
+    // 512 x 1024 projections have 128 tiles of 64 x 64, 256 of 32 x 64); env PIO_GEMM_T32=0: A/B switch
+    static const bool t32_on = [] {
+        const char *e = getenv("PIO_GEMM_T32");
+        return !e || atoi(e) != 0;
+    }();
+    const int64_t tiles64 = (int64_t)((g.M + 63) / 64) * ((p.n_store + 63) / 64) * g.batch;
+    const bool tiny = small && t32_on && gemm_kernel_choice() == 0 && 3 * tiles64 < 2 * (int64_t)cu_budget();
+    gemm_log(tiny ? "t32" : small ? "t64" : "t128", g, p);
     if (small) {
         p.tiles_n = (p.n_store + 63) / 64;
-        grid = dim3((unsigned)(((g.M + 63) / 64) * p.tiles_n), (unsigned)g.batch, 1);
+        grid = dim3((unsigned)(((g.M + (tiny ? 31 : 63)) / (tiny ? 32 : 64)) * p.tiles_n), (unsigned)g.batch, 1);
     }
     // 128 x 128 tiles on problems of at most ONE workgroup per CU (nobody covers a wave's wait for its next operand
     // stage): the four-stage LDS-DMA ring instead of the double buffer -- measured level on the flow stack's q|k|v GEMM
@@ -576,7 +584,8 @@ int gemm_nt_launch(const pio_gemm_t &g, hipStream_t s) {
     const bool ring128 = !small && ring128_on && tiles128 <= cu_budget();
 #define PIO_G128(DTV, KINDV)                                                                            \
     do {                                                                                                \
-        if (small) hipLaunchKernelGGL((gemm_nt_128<DTV, KINDV, 64, 64, 4>), grid, block, 0, s, p);      \
+        if (tiny) hipLaunchKernelGGL((gemm_nt_128<DTV, KINDV, 32, 64, 4>), grid, block, 0, s, p);       \
+        else if (small) hipLaunchKernelGGL((gemm_nt_128<DTV, KINDV, 64, 64, 4>), grid, block, 0, s, p); \
         else if (ring128) hipLaunchKernelGGL((gemm_nt_128<DTV, KINDV, 128, 128, 4>), grid, block, 0, s, p); \
         else hipLaunchKernelGGL((gemm_nt_128<DTV, KINDV, 128, 128, 2>), grid, block, 0, s, p);          \
     } while (0)
