@@ -173,6 +173,7 @@ class Attention(_HipModule):
                 bv = self.proj_v.bias.double() if self.proj_v.bias is not None else torch.zeros(kin, device=Wv.device)
                 bo = self.final.bias.double() if self.final.bias is not None else 0.0
                 kq = R.PackedLinear(Wk.t().float().contiguous(), None, 1, 1, dtype, True, k_channels=False)
+                # (always a pair: a single image under "fp16x2af" saves 0.2 % of the step and costs 6.05e-4 -> 6.35e-4)
                 vo = R.PackedLinear((Wo @ Wv).float().contiguous(), (Wo @ bv + bo).float().contiguous(), 1, 1, dtype,
                                     True, k_channels=False)
             d.kq, d.vo = kq.desc, vo.desc
