@@ -62,7 +62,7 @@ __device__ __forceinline__ int vrow_swz(int r) {
 // LDS at the end.  For the shapes that offer only one 4-wave workgroup per CU: the flow stack (16 heads x 2048 latents:
 // 256 workgroups of ~1 900 cycles per 64-key tile against 256 cycles of MFMAs), small ImageNet batches.
 template <int DT, int DK, int DV, bool VROW, int NW, int KS = 1>
-__global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void flash_attn_kernel(const FlashParams p) {
+__global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : 2) void flash_attn_kernel(const FlashParams p) {
     typedef typename Op<DT>::T T;
     typedef typename Op<DT>::V8 V8;
     typedef typename Op<DT>::V4 V4;
@@ -78,9 +78,9 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void flash_attn_kernel(co
     constexpr int NDT = DV / 32;                 // 32-row O^T tiles
     constexpr int NQS = DK / 16;                 // k-steps of the Q.K product
     constexpr int OROW = DV * 2 + 16;            // epilogue staging: bytes per output row (+16: rows spread over banks)
-    static_assert(KS == 1 || (KS == 2 && NW == 8), "key split: two groups of four waves");
+    static_assert(KS == 1 || ((KS == 2 || KS == 4) && NW == 4 * KS), "key split: KS groups of four waves");
     constexpr int NWQ = NW / KS;                 // waves along the query axis
-    constexpr int MRG = KS == 2 ? NWQ * 64 * (NDT * 16 + 2) * 4 : 0;   // merge area: (O^T, m, l) of the second key half
+    constexpr int MRG = KS > 1 ? (KS - 1) * NWQ * 64 * (NDT * 16 + 2) * 4 : 0;   // merge area: (O^T, m, l) of the other key parts
     constexpr int RING = 2 * KS * (K_TILE + V_TILE), OSTG = NW * 32 * OROW;
     constexpr int SM0 = RING > OSTG ? RING : OSTG;
     __shared__ __attribute__((aligned(16))) char smem[SM0 > MRG ? SM0 : MRG];
@@ -289,12 +289,14 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void flash_attn_kernel(co
         }
     }
 
-    if constexpr (KS == 2) {
-        // ---- merge the two key halves: the second half parks (O^T, m, l) in LDS (the ring is free behind the barrier),
-        // the first half folds it in: m = max(m0, m1), O = O0 2^(m0 - m) + O1 2^(m1 - m), l likewise (per-lane partials)
+    if constexpr (KS > 1) {
+        // ---- merge the key parts: parts 1 .. KS-1 park (O^T, m, l) in LDS (the ring is free behind the barrier), part 0
+        // folds them in one after the other: m = max(m0, m1), O = O0 2^(m0 - m) + O1 2^(m1 - m), l likewise (per-lane
+        // partials)
         __syncthreads();
-        float *mg = (float *)smem + (size_t)(qb * 64 + lane) * (NDT * 16 + 2);
-        if (kh == 1) {
+        constexpr int MW = NDT * 16 + 2;
+        if (kh > 0) {
+            float *mg = (float *)smem + (size_t)(((kh - 1) * NWQ + qb) * 64 + lane) * MW;
 #pragma unroll
             for (int d = 0; d < NDT; ++d)
 #pragma unroll
@@ -304,15 +306,19 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void flash_attn_kernel(co
         }
         __syncthreads();
         if (kh == 0) {
-            const float m1 = mg[NDT * 16], l1 = mg[NDT * 16 + 1];
-            const float m = fmaxf(m_run, m1);
-            const float a0 = __builtin_amdgcn_exp2f(m_run - m), a1 = __builtin_amdgcn_exp2f(m1 - m);
 #pragma unroll
-            for (int d = 0; d < NDT; ++d)
+            for (int part = 1; part < KS; ++part) {
+                const float *mg = (const float *)smem + (size_t)(((part - 1) * NWQ + qb) * 64 + lane) * MW;
+                const float m1 = mg[NDT * 16], l1 = mg[NDT * 16 + 1];
+                const float m = fmaxf(m_run, m1);
+                const float a0 = __builtin_amdgcn_exp2f(m_run - m), a1 = __builtin_amdgcn_exp2f(m1 - m);
 #pragma unroll
-                for (int j = 0; j < 16; ++j) oacc[d][j] = oacc[d][j] * a0 + mg[d * 16 + j] * a1;
-            l_run = l_run * a0 + l1 * a1;
-            m_run = m;
+                for (int d = 0; d < NDT; ++d)
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) oacc[d][j] = oacc[d][j] * a0 + mg[d * 16 + j] * a1;
+                l_run = l_run * a0 + l1 * a1;
+                m_run = m;
+            }
         }
     }
     // ---- epilogue: combine the two half-column sums, normalise, store O[q][h*DV + d]
@@ -323,7 +329,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void flash_attn_kernel(co
         // stores 16 contiguous bytes, DV / 8 lanes one row -- instead of 8-byte pieces of 32 different rows per
         // instruction (stamps of the pipelined kernel below: that form spent 8.7 k cycles per workgroup issuing stores).
         __syncthreads();
-        if (kh != 0) return;                     // (KS == 2: the first key half's waves hold the merged result)
+        if (kh != 0) return;                     // (KS > 1: the first key part's waves hold the merged result)
         char *const ost = smem + qb * (32 * OROW);
         char *const orow = ost + r32 * OROW;
 #pragma unroll
@@ -447,7 +453,18 @@ int flash_attention_launch(int dtype, int dkp, int dvp, int dk_logical, const vo
     }();
     const bool ksplit = ksplit_on && v_rowmajor && !wide && Tk >= 256 && (Tk % 128) == 0 &&
                         (int64_t)B * H * nqt <= cu_budget();
-    if (ksplit) {
+    // (four key parts = 16 waves per workgroup, four per SIMD: the narrow heads, whose waves need < 128 registers)
+    const bool ksplit4 = ksplit && dkp <= 64 && dvp <= 64 && Tk >= 1024 && (Tk % 256) == 0;
+    if (ksplit4) {
+        block = dim3(1024, 1, 1);
+        if (dkp == 64) {
+            if (dtype == PIO_DT_F16) hipLaunchKernelGGL((flash_attn_kernel<PIO_DT_F16, 64, 64, true, 16, 4>), grid, block, 0, s, p);
+            else hipLaunchKernelGGL((flash_attn_kernel<PIO_DT_BF16, 64, 64, true, 16, 4>), grid, block, 0, s, p);
+        } else {
+            if (dtype == PIO_DT_F16) hipLaunchKernelGGL((flash_attn_kernel<PIO_DT_F16, 32, 32, true, 16, 4>), grid, block, 0, s, p);
+            else hipLaunchKernelGGL((flash_attn_kernel<PIO_DT_BF16, 32, 32, true, 16, 4>), grid, block, 0, s, p);
+        }
+    } else if (ksplit) {
         block = dim3(512, 1, 1);
 #define PIO_FLASH_KS(DKV, DVV)                                                                                        \
     do {                                                                                                              \
