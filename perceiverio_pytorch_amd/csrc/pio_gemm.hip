@@ -560,14 +560,21 @@ int gemm_nt_launch(const pio_gemm_t &g, hipStream_t s) {
     // 64 x 64 tiles when the 128 x 128 tiling would leave most CUs without a tile (small batches: the 2048-row latent
     // stack of the flow model at B = 1 has 64 tiles of 128 x 128 per GEMM, 256 of 64 x 64); override 64 forces them
     const int64_t tiles128 = (int64_t)tiles_m * p.tiles_n * g.batch;
-    const bool small = gemm_kernel_choice() == 64 || (gemm_kernel_choice() == 0 && tiles128 < 192);
+    // ... and up to ONE 128 x 128 tile per CU (the double buffer then has no second workgroup to hide its waits behind) when
+    // the 64 x 64 tiling fills whole rounds of the chip's 512 resident workgroups or K is short: same box, ms per forward
+    // (tools/latency_probe.py / ab_env.py): ImageNet B = 8 (4096 x 1024 x 1024 projections: 256 -> 1024 tiles) 7.63 -> 7.27,
+    // flow (q|k|v 2048 x 1536 x 512: 192 -> 768 tiles) 5.31 -> 5.24; NOT the B = 2 q|k|v (1024 x 3072 x 1024: 192 -> 768
+    // tiles = 1.5 rounds of 16 K steps): 4.11 -> 4.18.
+    const int64_t tiles64_all = (int64_t)((g.M + 63) / 64) * ((p.n_store + 63) / 64) * g.batch;
+    const bool one_round = tiles128 <= cu_budget() && (g.K <= 512 || tiles64_all % (2 * (int64_t)cu_budget()) == 0);
+    const bool small = gemm_kernel_choice() == 64 || (gemm_kernel_choice() == 0 && (tiles128 < 192 || one_round));
     // ... and 32 x 64 tiles when even the 64 x 64 tiling leaves a third of the CUs without one (ImageNet B = 1: the
     // 512 x 1024 projections have 128 tiles of 64 x 64, 256 of 32 x 64); env PIO_GEMM_T32=0: A/B switch
     static const bool t32_on = [] {
         const char *e = getenv("PIO_GEMM_T32");
         return !e || atoi(e) != 0;
     }();
-    const int64_t tiles64 = (int64_t)((g.M + 63) / 64) * ((p.n_store + 63) / 64) * g.batch;
+    const int64_t tiles64 = tiles64_all;
     const bool tiny = small && t32_on && gemm_kernel_choice() == 0 && 3 * tiles64 < 2 * (int64_t)cu_budget();
     gemm_log(tiny ? "t32" : small ? "t64" : "t128", g, p);
     if (small) {
