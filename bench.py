@@ -96,7 +96,7 @@ CONFIGS = {
                              decoder_query_residual=False, final_project=True),
                  hot=dict(M=182528, C=322, Q=182528)),
     "multimodal": dict(golden="model_multimodal_full", parity_golden="model_multimodal_full", batch=1,
-                       policy="fp16x2w/fp16x3f",
+                       policy="fp16x2w/fp16x2afo",
                        gflop=250.1 + 128 * 57.2, scaling="weak",
                        metric="samples/sec PerceiverIO fwd (multimodal autoencode, 16x224x224 video + audio + label, "
                               "784x512 latents, 128 output chunks)",

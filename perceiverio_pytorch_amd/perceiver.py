@@ -225,7 +225,7 @@ class PerceiverDecoder(nn.Module):
         key = R.param_key(self.final_layer.weight, self.final_layer.bias)
         if self._final_cache is None or self._final_cache[0] != key:
             dtype, wlevel, _split = R.policy_dtype()
-            two = wlevel >= 2
+            two = wlevel >= 2 or "final_layer" in R.policy_fine_split()
             self._final_cache = (key, R.PackedLinear(self.final_layer.weight, self.final_layer.bias, 1, 1, dtype, two))
         return self._final_cache[1]
 

@@ -45,10 +45,16 @@ _POLICIES = {"fp16": (L.PIO_DT_F16, 0, False), "fp16x2s": (L.PIO_DT_F16, 1, Fals
              "fp16sd": (L.PIO_DT_F16, 0, False),
              # finer weight splits of a self-attend stack (round 4): only the out projection ("final"), or only proj_v, of
              # the two that "x2s" splits -- a second K sweep costs its GEMM's time again
-             "fp16x2o": (L.PIO_DT_F16, 0, False), "fp16x2v": (L.PIO_DT_F16, 0, False)}
-# weights split under the fine policies (beside the level of _POLICIES): names of Attention's linears
-_FINE_SPLIT = {"fp16x2o": {"final"}, "fp16x2v": {"proj_v"}}
-_FUSED_CORE = {"fp16x3f", "bf16x3f", "fp16x2af"}
+             "fp16x2o": (L.PIO_DT_F16, 0, False), "fp16x2v": (L.PIO_DT_F16, 0, False),
+             # x2afo: "x2af" (split activations around the single-sweep fused core) + split WEIGHTS on the output side of a
+             # decoder only -- the attention's out projection, the decoder's final_layer, the heads behind it -- where a
+             # dense-output model has nothing left to average a weight's rounding away (multimodal, second seed: x2af
+             # 1.01e-3 / 1.14e-3, x2afo 4.0e-4 / 5.3e-4 at +4 % time; x3f 0.6e-4 / 2.7e-4 at +17 %)
+             "fp16x2afo": (L.PIO_DT_F16, 0, True)}
+# weights split under the fine policies (beside the level of _POLICIES): Attention: proj_v, final; MLP: fc1, fc2; decoder:
+# final_layer; heads behind the decoder (hip_linear): post
+_FINE_SPLIT = {"fp16x2o": {"final"}, "fp16x2v": {"proj_v"}, "fp16x2afo": {"final", "final_layer", "post"}}
+_FUSED_CORE = {"fp16x3f", "bf16x3f", "fp16x2af", "fp16x2afo"}
 _BLOCK_FEEDBACK = {"fp16sd"}
 _policy = os.environ.get("PIO_PRECISION", "fp16x3")
 if _policy not in _POLICIES:
@@ -172,8 +178,10 @@ def capturing(device: torch.device) -> bool:
 
 
 def policy_fine_split(name: Optional[str] = None) -> set:
-    """Names of the Attention linears whose weights are (hi, lo) pairs beyond what the policy's level says."""
-    return _FINE_SPLIT.get(name or _policy, set())
+    """Names of the linears whose weights are (hi, lo) pairs beyond what the policy's level says (Attention: proj_v, final;
+    MLP: fc1, fc2; decoder: final_layer; heads behind the decoder: post)."""
+    extra = set(os.environ.get("PIO_EXTRA_SPLIT", "").split(",")) - {""}      # (A/B experiments: tools/)
+    return _FINE_SPLIT.get(name or _policy, set()) | extra
 
 
 def policy_core_single(name: Optional[str] = None) -> bool:
@@ -564,7 +572,7 @@ def hip_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tenso
     key = param_key(weight, bias)
     pk = cache.get("packed")
     if pk is None or pk[0] != key:
-        pk = (key, PackedLinear(weight, bias, 1, 1, dtype, wlevel >= 2))
+        pk = (key, PackedLinear(weight, bias, 1, 1, dtype, wlevel >= 2 or "post" in policy_fine_split()))
         cache["packed"] = pk
     lin = pk[1]
     lead = x.shape[:-1]

@@ -260,9 +260,10 @@ class MLP(_HipModule):
     def _build_desc(self, ov=None):
         dtype, wlevel, split = R.policy_dtype()
         two = wlevel >= 2
+        fine = R.policy_fine_split()
         wt = (lambda lin: ov[lin]) if ov else (lambda lin: lin.weight)
-        f1 = R.PackedLinear(wt(self.fc1), self.fc1.bias, 1, 1, dtype, two, n_channels=True)
-        f2 = R.PackedLinear(wt(self.fc2), self.fc2.bias, 1, 1, dtype, two)
+        f1 = R.PackedLinear(wt(self.fc1), self.fc1.bias, 1, 1, dtype, two or "fc1" in fine, n_channels=True)
+        f2 = R.PackedLinear(wt(self.fc2), self.fc2.bias, 1, 1, dtype, two or "fc2" in fine)
         d = L.Mlp(f1.desc, f2.desc, self.fc1.in_features, self.fc1.out_features, self.fc2.out_features, dtype,
                   int(split))
         return d, [f1, f2]
