@@ -84,7 +84,7 @@ struct LnFold {
 // y[rows, n] = x16[rows, lin.k] * W^T (+bias) (act) (+R); a 16-bit output has ldc = lin.n (padded).
 static int linear_fwd(const pio_linear_t &lin_plain, int dtype, Pair x, int64_t rows, void *y, void *y_lo, bool out_f32,
                       int n_logical, int64_t ldc, int act, const Residual *res, hipStream_t s,
-                      const LnFold *fold = nullptr) {
+                      const LnFold *fold = nullptr, int n_store16 = 0) {
     const pio_linear_t &lin = (fold && fold->in_part) ? *fold->w : lin_plain;
     pio_gemm_t g = gemm_defaults(dtype);
     if (fold && fold->in_part) {
@@ -125,7 +125,7 @@ static int linear_fwd(const pio_linear_t &lin_plain, int dtype, Pair x, int64_t 
     g.bias_mode = lin.bias ? 1 : 0;
     g.act = act;
     g.out_f32 = out_f32 ? 1 : 0;
-    g.n_store = g.N;
+    g.n_store = (!out_f32 && n_store16 > g.N) ? n_store16 : g.N;   // (16-bit rows zero-filled up to the channel pitch)
     if (res && res->ptr && !(fold && fold->res16_hi)) {
         g.R = res->ptr;
         g.ldr = res->ld;
@@ -475,12 +475,18 @@ static int attention_core(const pio_attention_t &a, Pair xq, bool q_bcast, Pair 
 // ------------------------------------------------------------------------------------------------------
 // MLP core on a 16-bit input
 // ------------------------------------------------------------------------------------------------------
+// out16 (optional; then `out` is not written): the result leaves as the 16-bit operand (pair under split activations) of
+// the GEMM that follows -- rows of padc(m.out) elements, zero-filled behind the logical columns -- instead of as fp32 rows
+// that a cast pass would re-read (the decoders' y in front of their final Linear).
 static int mlp_core(const pio_mlp_t &m, Pair x, int64_t rows, Pair h, const Residual *res, float *out,
                     hipStream_t s, const LnFold *fold_in = nullptr, const LnFold *fold_out = nullptr,
-                    int64_t out_ld = 0) {
+                    int64_t out_ld = 0, const Pair *out16 = nullptr) {
     if (!out_ld) out_ld = m.out;
     if (m.fc1.k != padc(m.in) || m.fc1.n != padc(m.hidden) || m.fc2.k != m.fc1.n) return PIO_E_SHAPE;
     PIO_TRY(linear_fwd(m.fc1, m.dtype, x, rows, h.hi, h.lo, false, 0, m.fc1.n, 1, nullptr, s, fold_in));
+    if (out16)
+        return linear_fwd(m.fc2, m.dtype, h, rows, out16->hi, out16->lo, false, 0, padc(m.out), 0, res, s, nullptr,
+                          padc(m.out));
     return linear_fwd(m.fc2, m.dtype, h, rows, out, nullptr, true, m.out, out_ld, 0, res, s, fold_out);
 }
 
@@ -750,7 +756,7 @@ static int cross_attention_run(const pio_cross_attention_t &ca, const pio_tensor
                                const uint8_t *kv_mask, const uint8_t *q_mask, const uint8_t *full_mask,
                                const float *attention_bias, float *out, float *probs_out, CrossPlan &p,
                                hipStream_t s, const pio_tensor3_t *ikv_tail = nullptr, int64_t out_ld = 0,
-                               const QCache *qc = nullptr) {
+                               const QCache *qc = nullptr, const Pair *out16 = nullptr) {
     const int B = iq.B, Tq = iq.T, Tk = ikv.T;
     const int64_t rows = (int64_t)B * Tq;
     const int kv_c = ikv.C + (ikv_tail ? ikv_tail->C : 0);
@@ -774,7 +780,7 @@ static int cross_attention_run(const pio_cross_attention_t &ca, const pio_tensor
     const Pair qm = pair_if(p.q16, ca.mlp.act_split);
     PIO_TRY(cast_pair(t1, &ca.ln2, qm, padc(iq.C), ca.mlp.dtype, s));
     const Residual r1 = residual_of(t1);
-    return mlp_core(ca.mlp, qm, rows, p.h16, &r1, out, s, nullptr, nullptr, out_ld);
+    return mlp_core(ca.mlp, qm, rows, p.h16, &r1, out, s, nullptr, nullptr, out_ld, out16);
 }
 
 struct DecoderPlan {
@@ -1015,13 +1021,20 @@ int pio_decoder_fwd_qcache(const pio_cross_attention_t *cross, const pio_linear_
     // perceiver.py:172-177: mask[b,i,j] = query_mask[b,i]
     float *y = final_layer ? p.y : out;
     const int64_t y_ld = final_layer ? pitch4(query->C) : query->C;  // (y is internal when a final layer follows)
+    // (with a final Linear the cross-attend's result is only ever its operand: fc2 writes it as 16-bit rows directly --
+    //  env PIO_DEC_Y16=0: the fp32 rows + cast pass of rounds 1-3, for A/B)
+    static const bool y16_direct = [] {
+        const char *e = getenv("PIO_DEC_Y16");
+        return !e || atoi(e) != 0;
+    }();
+    const bool direct = final_layer && y16_direct && final_layer->k == padc(query->C);
     PIO_TRY(cross_attention_run(*cross, *query, *latents, nullptr, query_mask, nullptr, nullptr, y, nullptr, p.cp,
-                                s, nullptr, y_ld, qc));
+                                s, nullptr, y_ld, qc, direct ? &p.y16 : nullptr));
     if (!final_layer) return PIO_OK;
     // perceiver.py:178-179: final nn.Linear on every query row
     if (final_layer->k != padc(query->C)) return PIO_E_SHAPE;
     const pio_tensor3_t ty = {y, (int64_t)Q * y_ld, y_ld, B, Q, query->C};
-    PIO_TRY(cast_pair(ty, nullptr, p.y16, padc(query->C), cross->attn.dtype, s));
+    if (!direct) PIO_TRY(cast_pair(ty, nullptr, p.y16, padc(query->C), cross->attn.dtype, s));
     return linear_fwd(*final_layer, cross->attn.dtype, p.y16, (int64_t)B * Q, out, nullptr, true, final_out, final_out,
                       0, nullptr, s);
 }

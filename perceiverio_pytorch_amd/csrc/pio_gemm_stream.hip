@@ -538,7 +538,12 @@ bool gemm_stream_ok(const GemmParams &p, int batch) {
     if ((p.N & 3) || (p.n_store & 3) || !p.vec_ok) return false;
     if (p.act != 0 && p.act != 1) return false;
     if (p.alpha == 0.0f) return false;
-    if (p.R && (!p.r_vec || p.alpha != 1.0f || p.act != 0 || p.r_rows != 0 || !p.out_f32)) return false;
+    // (a residual with a 16-bit result -- the decoder's fc2 leaving y as the operand of the final Linear -- rides the same
+    //  way: the residual is loaded into the vacated accumulators, the output form is the epilogue's business)
+    if (p.R && (!p.r_vec || p.alpha != 1.0f || p.act != 0 || p.r_rows != 0)) return false;
+    // (... as ONE 16-bit array: the hi + lo pair form of that variant spills 11 registers, which the counted waits of this
+    //  kernel cannot carry -- those launches go to gemm_nt_256)
+    if (p.R && !p.out_f32 && p.C_lo) return false;
     if (p.out_f32 && p.act != 0) return false;
     if (p.out_f32 && p.C_lo) return false;
     // per-lane DMA offsets are 32-bit byte offsets inside one (batch, head) slice
@@ -556,7 +561,8 @@ void gemm_stream_launch(const GemmParams &p, int dtype, int batch, hipStream_t s
     dim3 grid((unsigned)G, 1, 1), block(512, 1, 1);
 #define PIO_GK(DTV, R, ACT, OUT) hipLaunchKernelGGL((gemm_nt_stream<DTV, R, ACT, OUT>), grid, block, 0, s, p, tiles_m, tiles_n, batch)
 #define PIO_GS(DTV)                                                      \
-    if (p.R) PIO_GK(DTV, true, 0, 2);                                    \
+    if (p.R && p.out_f32) PIO_GK(DTV, true, 0, 2);                       \
+    else if (p.R) PIO_GK(DTV, true, 0, 0);                               \
     else if (p.out_f32) PIO_GK(DTV, false, 0, 2);                        \
     else if (p.act == 1 && p.C_lo) PIO_GK(DTV, false, 1, 1);             \
     else if (p.act == 1) PIO_GK(DTV, false, 1, 0);                       \
