@@ -20,6 +20,19 @@ namespace pio {
 
 __device__ __attribute__((aligned(16))) uint32_t g_zero_chunk[4] = {0, 0, 0, 0};
 
+#ifdef PIO_G128_STAMPS
+// Dev-only (tools/g128_stamps.py builds a private copy of the library with this flag): thread 0 of one workgroup records
+// s_memtime at four points of each of the first 30 K steps (in LDS: stores would count in vmcnt), and at the kernel's edges.
+__device__ unsigned long long g128_stamps[128];
+__device__ int g128_block;
+#define G128_STAMP(i)                                                                  \
+    do {                                                                               \
+        if (stamp_on && (i) < 128) stamp_lds[i] = __builtin_readcyclecounter();        \
+    } while (0)
+#else
+#define G128_STAMP(i)
+#endif
+
 constexpr int BM = 128, BN = 128, BK = 64;   // the default tile (launcher arithmetic); the kernel is templated on TM x TN
 
 // KIND only tags the instantiation (0: one flat [rows,K]x[N,K] linear, 1: batched attention product) so that
@@ -34,8 +47,13 @@ constexpr int BM = 128, BN = 128, BK = 64;   // the default tile (launcher arith
 // double buffer a 64 x 64 x 1024 tile spent ~1.9 k cycles per 64-deep step (the latency of one LDS-DMA round trip under
 // load) on 128 cycles of MFMAs.  (A six-stage ring -- four steps in flight, 96 KiB, one workgroup per CU -- measured no
 // better than four stages with two workgroups per CU: DESIGN_LOG R3.3.)
-template <int DT, int KIND, int TM, int TN, int NS>
-__global__ __launch_bounds__(256) void gemm_nt_128(const GemmParams p) {
+// KG: K groups.  2 = EIGHT waves, two teams of four that each run the whole loop below on every other 64-deep K step
+// (own ring, own accumulators; the row pass sums the two epilogue images).  An LDS-DMA piece of 16 bytes a lane holds its
+// wave for ~150 cycles (tools/g128_stamps.py: the 3-4 pieces of a step are ~440 of its ~700 cycles, four waves together
+// reach 27 B/clk where tools/dma_bench.hip needs eight for the path's 54): a tile that owns its CU alone gets the second
+// team instead of a second workgroup.
+template <int DT, int KIND, int TM, int TN, int NS, int KG = 1>
+__global__ __launch_bounds__(256 * KG) void gemm_nt_128(const GemmParams p) {
     typedef typename Op<DT>::T T;
     typedef typename Op<DT>::V8 V8;
     constexpr int A_BYTES = TM * BK * 2, B_BYTES = TN * BK * 2;     // operand tiles: rows x 128 bytes
@@ -43,14 +61,22 @@ __global__ __launch_bounds__(256) void gemm_nt_128(const GemmParams p) {
     constexpr int MI = TM / 32, NI = TN / 32;                        // 16 x 16 units per wave (waves as 2 x 2)
     constexpr int EPI_BYTES = TM * TN * 4;
     // (+ TM x (rstd, -mean rstd) behind the epilogue image: the LayerNorm fold's consumer)
-    constexpr int SMEM = (NS * (A_BYTES + B_BYTES) > EPI_BYTES ? NS * (A_BYTES + B_BYTES) : EPI_BYTES) + TM * 8;
+    constexpr int TEAM_BYTES = NS * (A_BYTES + B_BYTES);           // one team's ring
+    constexpr int SMEM = KG * (TEAM_BYTES > EPI_BYTES ? TEAM_BYTES : EPI_BYTES) + TM * 8;
     static_assert(NS == 2 || (NS - 2) * (A_PPW + B_PPW) <= 63, "the counted wait must fit vmcnt");
     __shared__ __attribute__((aligned(16))) char smem[SMEM];        // A stages, B stages (then the epilogue image)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = __builtin_amdgcn_readfirstlane((tid >> 6) & 3);   // inside the team
+    const int kg = KG == 1 ? 0 : __builtin_amdgcn_readfirstlane(tid >> 8);
+    char *const ring = smem + kg * TEAM_BYTES;
     const int wm = wave >> 1, wn = wave & 1;
+#ifdef PIO_G128_STAMPS
+    __shared__ unsigned long long stamp_lds[128];
+    const bool stamp_on = (int)blockIdx.x == g128_block && blockIdx.y == 0 && tid == 0;
+    G128_STAMP(120);
+#endif
 
     const int tile_n = blockIdx.x % p.tiles_n;
     const int tile_m = blockIdx.x / p.tiles_n;
@@ -86,16 +112,16 @@ __global__ __launch_bounds__(256) void gemm_nt_128(const GemmParams p) {
     }
     const T *zsrc = (const T *)g_zero_chunk;
 
-    const int nk1 = (p.K + BK - 1) / BK;
+    const int nk1 = (p.K + BK * KG - 1) / (BK * KG);   // steps per pass (of one team)
     const int nk = p.npass * nk1;
 
     auto stage = [&](int kt, int buf) {
         const int pass = (kt >= nk1) + (kt >= 2 * nk1);   // wave-uniform
-        const int k0 = (kt - pass * nk1) * BK;
+        const int k0 = ((kt - pass * nk1) * KG + kg) * BK;   // (a team's step past K reads the zero chunk)
         const int64_t dA = pass == 0 ? 0 : (pass == 1 ? p.dA1 : p.dA2);
         const int64_t dB = pass == 0 ? 0 : (pass == 1 ? p.dB1 : p.dB2);
-        char *abase = smem + buf * A_BYTES;
-        char *bbase = smem + NS * A_BYTES + buf * B_BYTES;
+        char *abase = ring + buf * A_BYTES;
+        char *bbase = ring + NS * A_BYTES + buf * B_BYTES;
 #pragma unroll
         for (int i = 0; i < A_PPW; ++i) {
             const T *sa = (k0 + a_koff[i]) < p.K ? (a_src[i] + k0 + dA) : zsrc;
@@ -136,10 +162,30 @@ __global__ __launch_bounds__(256) void gemm_nt_128(const GemmParams p) {
         for (int j = 0; j < NS - 1; ++j) stage(j < nk ? j : 0, j);
     }
     int slot = 0;  // (NS > 2) ring slot of step kt
+    G128_STAMP(121);
     for (int kt = 0; kt < nk; ++kt) {
+        G128_STAMP(kt < 30 ? kt * 4 : 127);
+        const int cur = NS == 2 ? (kt & 1) : slot;
+        const char *abase = ring + cur * A_BYTES;
+        const char *bbase = ring + NS * A_BYTES + cur * B_BYTES;
+        V8 af[2][MI], bf[2][NI];
+        // the step's fragment reads go out BEFORE the next stage's DMA pieces (whose issue holds the wave for ~130 cycles a
+        // piece with all four waves at the TA together: tools/g128_stamps.py), so the LDS latency passes under the issue
+        auto frags = [&]() {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int coff = ((ks * 4 + fchunk) ^ fswz) << 4;
+#pragma unroll
+                for (int i = 0; i < MI; ++i) af[ks][i] = *(const V8 *)(abase + a_off[i] + coff);
+#pragma unroll
+                for (int i = 0; i < NI; ++i) bf[ks][i] = *(const V8 *)(bbase + b_off[i] + coff);
+            }
+        };
         if constexpr (NS == 2) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
+            G128_STAMP(kt < 30 ? kt * 4 + 1 : 127);
+            frags();
             if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
         } else {
             // all but the youngest NS-2 steps' pieces have landed: step kt is complete in this wave's share, after the
@@ -147,35 +193,31 @@ __global__ __launch_bounds__(256) void gemm_nt_128(const GemmParams p) {
             // MFMAs), whose slot takes step kt+NS-1.  A raw s_barrier: __syncthreads() would drain vmcnt to zero.
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * (A_PPW + B_PPW)) : "memory");
             __builtin_amdgcn_s_barrier();
+            G128_STAMP(kt < 30 ? kt * 4 + 1 : 127);
             const int nslot = slot == 0 ? NS - 1 : slot - 1;
+            frags();
+            G128_STAMP(kt < 30 ? kt * 4 + 3 : 127);   // (the stamp's own lgkmcnt(0) waits for the fragment reads)
             stage(kt + NS - 1 < nk ? kt + NS - 1 : 0, nslot);
         }
-        const int cur = NS == 2 ? (kt & 1) : slot;
+        G128_STAMP(kt < 30 ? kt * 4 + 2 : 127);
         if constexpr (NS != 2) slot = slot + 1 == NS ? 0 : slot + 1;
-        const char *abase = smem + cur * A_BYTES;
-        const char *bbase = smem + NS * A_BYTES + cur * B_BYTES;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int coff = ((ks * 4 + fchunk) ^ fswz) << 4;
-            V8 af[MI], bf[NI];
-#pragma unroll
-            for (int i = 0; i < MI; ++i) af[i] = *(const V8 *)(abase + a_off[i] + coff);
-#pragma unroll
-            for (int i = 0; i < NI; ++i) bf[i] = *(const V8 *)(bbase + b_off[i] + coff);
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = Op<DT>::mfma16(bf[ni], af[mi], acc[mi][ni]);
-        }
+                for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = Op<DT>::mfma16(bf[ks][ni], af[ks][mi], acc[mi][ni]);
     }
 
     // ---- epilogue through LDS: the accumulators (lane = one row, 4 consecutive columns) are parked in a
     // [TM][TN] fp32 image (16-byte chunks XOR-swizzled by row, conflict-free both ways) so that the
     // bias / GELU / residual / store pass walks whole rows: a wave touches 2 rows x 512 contiguous bytes
     // (fp32) or 2 rows x 256 bytes (16-bit) per instruction instead of 16 rows x 64 bytes.
+    G128_STAMP(122);
     if constexpr (NS != 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the ring's surplus pieces: land before the image)
     __syncthreads();  // every wave is done reading the last operand tile
-    float *cs = (float *)smem;
+    G128_STAMP(123);
+    float *cs = (float *)smem + kg * (TM * TN);   // (team kg's image; both are summed in the row pass)
     constexpr int CPR = TN / 4;  // 16-byte chunks per image row (32 or 16)
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
@@ -207,6 +249,8 @@ __global__ __launch_bounds__(256) void gemm_nt_128(const GemmParams p) {
         stat[2 * tid + 1] = -mean * rstd;
     }
     __syncthreads();
+    if (KG > 1 && tid >= 256) return;   // the row pass belongs to the first team (no barrier below)
+    cs = (float *)smem;
     const int64_t coffz = zb * p.sCb + zh * p.sCh;
     const int c = tid & (CPR - 1);
     constexpr int RPI = 256 / CPR;  // rows per pass of the 256 threads (8 or 16)
@@ -235,6 +279,11 @@ __global__ __launch_bounds__(256) void gemm_nt_128(const GemmParams p) {
             const int m = tile_m * TM + ml;
             if (m >= p.M) break;  // rows are visited in increasing order
             f32x4 v = *(const f32x4 *)(cs + ml * TN + ((c ^ (ml & (CPR - 1))) << 2));
+            if constexpr (KG > 1) {
+                const f32x4 v2 = *(const f32x4 *)(cs + TM * TN + ml * TN + ((c ^ (ml & (CPR - 1))) << 2));
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += v2[r];
+            }
             if (p.row_part) {
                 // ---- fold producer (launcher: N % 64 == 0, n_store == N, 16-bit rows 8-byte aligned): x = acc + bias +
                 // residual pair, leaves as the pair (X16, X16_lo) [+ fp32 C] with the row's (sum, sum of squares) over
@@ -332,7 +381,21 @@ __global__ __launch_bounds__(256) void gemm_nt_128(const GemmParams p) {
             }
         }
     }
+#ifdef PIO_G128_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    G128_STAMP(124);
+    if (stamp_on)
+        for (int i = 0; i < 128; ++i) g128_stamps[i] = stamp_lds[i];
+#endif
 }
+
+#ifdef PIO_G128_STAMPS
+extern "C" int pio_debug_g128_stamps(unsigned long long *out128, int block) {
+    if (out128 && hipMemcpyFromSymbol(out128, HIP_SYMBOL(g128_stamps), sizeof(g128_stamps)) != hipSuccess) return 1;
+    if (block >= 0 && hipMemcpyToSymbol(HIP_SYMBOL(g128_block), &block, sizeof(int)) != hipSuccess) return 2;
+    return 0;
+}
+#endif
 
 // kernel selection override (pio_gemm_kernel_override; initial value from env PIO_GEMM_TILE)
 static int &gemm_kernel_choice() {
@@ -589,9 +652,20 @@ int gemm_nt_launch(const pio_gemm_t &g, hipStream_t s) {
         return e && atoi(e) != 0;
     }();
     const bool ring128 = !small && ring128_on && tiles128 <= cu_budget();
+    // two K teams (eight waves) for small tiles that own their CU alone (see the kernel); env PIO_GEMM_KG2=0: A/B switch
+    static const bool kg2_on = [] {
+        const char *e = getenv("PIO_GEMM_KG2");
+        return !e || atoi(e) != 0;
+    }();
+    // (from K = 1024: the flow stack's 2048 x 512 x 512 projections -- four steps a team -- lose 2 % of a forward to it,
+    //  ImageNet B = 1 gains 5.6 %: tools/ab_env.py)
+    const bool kg2 = small && kg2_on && gemm_kernel_choice() == 0 && p.npass * g.K >= 1024 &&
+                     (int64_t)grid.x * grid.y <= (int64_t)cu_budget();
 #define PIO_G128(DTV, KINDV)                                                                            \
     do {                                                                                                \
-        if (tiny) hipLaunchKernelGGL((gemm_nt_128<DTV, KINDV, 32, 64, 4>), grid, block, 0, s, p);       \
+        if (tiny && kg2) hipLaunchKernelGGL((gemm_nt_128<DTV, KINDV, 32, 64, 4, 2>), grid, dim3(512, 1, 1), 0, s, p); \
+        else if (small && kg2) hipLaunchKernelGGL((gemm_nt_128<DTV, KINDV, 64, 64, 4, 2>), grid, dim3(512, 1, 1), 0, s, p); \
+        else if (tiny) hipLaunchKernelGGL((gemm_nt_128<DTV, KINDV, 32, 64, 4>), grid, block, 0, s, p);  \
         else if (small) hipLaunchKernelGGL((gemm_nt_128<DTV, KINDV, 64, 64, 4>), grid, block, 0, s, p); \
         else if (ring128) hipLaunchKernelGGL((gemm_nt_128<DTV, KINDV, 128, 128, 4>), grid, block, 0, s, p); \
         else hipLaunchKernelGGL((gemm_nt_128<DTV, KINDV, 128, 128, 2>), grid, block, 0, s, p);          \
