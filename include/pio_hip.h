@@ -418,6 +418,14 @@ int pio_decoder_fwd_qcache(const pio_cross_attention_t *cross, const pio_linear_
                            float *out, void *workspace, size_t workspace_bytes, void *stream, void *q16_hi,
                            void *q16_lo, int32_t q16_valid);
 
+/* PerceiverDecoder.forward (perceiver.py:166-180) with the query rows handed over as TWO arrays whose channels are
+ * concatenated, [query | query_tail] (query_tail->B == 1: one batch-invariant table) -- the dense decoders whose queries ARE
+ * the network's preprocessed input (flow_perceiver.py: FlowQuery = [conv features | Fourier position table]): layer_norm_q
+ * runs over the virtual concatenation, nothing is concatenated in HBM.  Needs use_query_residual == 0. */
+int pio_decoder_fwd_split(const pio_cross_attention_t *cross, const pio_linear_t *final_layer, int32_t final_out,
+                          const pio_tensor3_t *query, const pio_tensor3_t *query_tail, const pio_tensor3_t *latents,
+                          const uint8_t *query_mask, float *out, void *workspace, size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -142,6 +142,8 @@ SIGNATURES = {
     "pio_decoder_qcache_bytes": (_sz, [P(CrossAttention), _i32, _i32]),
     "pio_decoder_fwd_qcache": (C.c_int, [P(CrossAttention), P(Linear), _i32, P(Tensor3), P(Tensor3), _vp, _vp, _vp, _sz,
                                          _vp, _vp, _vp, _i32]),
+    "pio_decoder_fwd_split": (C.c_int, [P(CrossAttention), P(Linear), _i32, P(Tensor3), P(Tensor3), P(Tensor3), _vp, _vp, _vp,
+                                        _sz, _vp]),
 }
 
 _lib = None

@@ -751,17 +751,21 @@ struct CrossPlan {
 
 // ikv_tail (optional): the key / value input arrives as TWO arrays whose channels are concatenated, [ikv | ikv_tail]
 // (ikv_tail->B == 1: one batch-invariant table, e.g. Fourier position features); layer_norm_kv runs over the virtual
-// concatenation and nothing is ever concatenated in HBM.
+// concatenation and nothing is ever concatenated in HBM.  iq_tail (optional, blocks without a query residual): the same
+// for the query rows, [iq | iq_tail] under layer_norm_q (the dense decoders whose queries ARE the network's input).
 static int cross_attention_run(const pio_cross_attention_t &ca, const pio_tensor3_t &iq, const pio_tensor3_t &ikv,
                                const uint8_t *kv_mask, const uint8_t *q_mask, const uint8_t *full_mask,
                                const float *attention_bias, float *out, float *probs_out, CrossPlan &p,
                                hipStream_t s, const pio_tensor3_t *ikv_tail = nullptr, int64_t out_ld = 0,
-                               const QCache *qc = nullptr, const Pair *out16 = nullptr) {
+                               const QCache *qc = nullptr, const Pair *out16 = nullptr,
+                               const pio_tensor3_t *iq_tail = nullptr) {
     const int B = iq.B, Tq = iq.T, Tk = ikv.T;
     const int64_t rows = (int64_t)B * Tq;
     const int kv_c = ikv.C + (ikv_tail ? ikv_tail->C : 0);
-    if (iq.C != ca.attn.q_in || kv_c != ca.attn.k_in || kv_c != ca.attn.v_in || ikv.B != B) return PIO_E_SHAPE;
-    if (ca.attn.out != iq.C || ca.mlp.in != iq.C || ca.mlp.out != iq.C) return PIO_E_SHAPE;
+    const int q_c = iq.C + (iq_tail ? iq_tail->C : 0);
+    if (q_c != ca.attn.q_in || kv_c != ca.attn.k_in || kv_c != ca.attn.v_in || ikv.B != B) return PIO_E_SHAPE;
+    if (ca.attn.out != q_c || ca.mlp.in != q_c || ca.mlp.out != q_c) return PIO_E_SHAPE;
+    if (iq_tail && (ca.use_query_residual || qc || p.q_bcast)) return PIO_E_ARG;  // (the rows themselves are needed then)
     // layer_norm_kv, layer_norm_q  (transformer_primitives.py:379-380)
     if (ikv_tail)
         PIO_TRY(layernorm_cast_cat_launch(ikv, *ikv_tail, ca.ln_kv, p.kv16.hi, p.kv16.lo, padc(kv_c), ca.attn.dtype, s));
@@ -770,15 +774,17 @@ static int cross_attention_run(const pio_cross_attention_t &ca, const pio_tensor
     const pio_tensor3_t q1 = p.q_bcast ? first_batch(iq) : iq;
     const Pair qa = pair_if(p.q16, ca.attn.act_split);
     if (qc && ca.use_query_residual) return PIO_E_ARG;  // (the query rows themselves are needed then)
-    if (!(qc && qc->valid)) PIO_TRY(cast_pair(q1, &ca.ln_q, qa, padc(iq.C), ca.attn.dtype, s));
+    if (iq_tail)
+        PIO_TRY(layernorm_cast_cat_launch(iq, *iq_tail, ca.ln_q, qa.hi, qa.lo, padc(q_c), ca.attn.dtype, s));
+    else if (!(qc && qc->valid)) PIO_TRY(cast_pair(q1, &ca.ln_q, qa, padc(q_c), ca.attn.dtype, s));
     const Residual rq = residual_of(iq);
     PIO_TRY(attention_core(ca.attn, qa, p.q_bcast, p.kv16, p.kv16, B, Tq, Tk, kv_mask, q_mask, full_mask,
                            attention_bias, ca.use_query_residual ? &rq : nullptr, p.x1, probs_out, p.core, s, nullptr,
-                           nullptr, pitch4(iq.C), qc));
+                           nullptr, pitch4(q_c), qc));
     // x + MLP(LN2(x))  (transformer_primitives.py:401)
-    pio_tensor3_t t1 = {p.x1, (int64_t)Tq * pitch4(iq.C), pitch4(iq.C), B, Tq, iq.C};
+    pio_tensor3_t t1 = {p.x1, (int64_t)Tq * pitch4(q_c), pitch4(q_c), B, Tq, q_c};
     const Pair qm = pair_if(p.q16, ca.mlp.act_split);
-    PIO_TRY(cast_pair(t1, &ca.ln2, qm, padc(iq.C), ca.mlp.dtype, s));
+    PIO_TRY(cast_pair(t1, &ca.ln2, qm, padc(q_c), ca.mlp.dtype, s));
     const Residual r1 = residual_of(t1);
     return mlp_core(ca.mlp, qm, rows, p.h16, &r1, out, s, nullptr, nullptr, out_ld, out16);
 }
@@ -1004,11 +1010,12 @@ size_t pio_decoder_qcache_bytes(const pio_cross_attention_t *cross, int32_t Bq, 
     return (size_t)round_up((int64_t)Bq * Q * cross->attn.heads * cross->attn.dkp * 2, 256);
 }
 
-int pio_decoder_fwd_qcache(const pio_cross_attention_t *cross, const pio_linear_t *final_layer, int32_t final_out,
-                           const pio_tensor3_t *query, const pio_tensor3_t *latents, const uint8_t *query_mask,
-                           float *out, void *workspace, size_t workspace_bytes, void *stream, void *q16_hi,
-                           void *q16_lo, int32_t q16_valid) {
+static int decoder_run(const pio_cross_attention_t *cross, const pio_linear_t *final_layer, int32_t final_out,
+                       const pio_tensor3_t *query, const pio_tensor3_t *query_tail, const pio_tensor3_t *latents,
+                       const uint8_t *query_mask, float *out, void *workspace, size_t workspace_bytes, void *stream,
+                       void *q16_hi, void *q16_lo, int32_t q16_valid) {
     if (!cross || !query || !latents || !out || !workspace) return PIO_E_ARG;
+    const int q_c = query->C + (query_tail ? query_tail->C : 0);
     QCache qcache{{q16_hi, q16_lo}, q16_valid != 0};
     const QCache *qc = q16_hi ? &qcache : nullptr;
     if (qc && (((uintptr_t)q16_hi & 15) || ((uintptr_t)q16_lo & 15))) return PIO_E_ALIGN;
@@ -1020,23 +1027,39 @@ int pio_decoder_fwd_qcache(const pio_cross_attention_t *cross, const pio_linear_
     if (p.carve(workspace, *cross, final_layer, B, Q, N, qb) > workspace_bytes) return PIO_E_WORKSPACE;
     // perceiver.py:172-177: mask[b,i,j] = query_mask[b,i]
     float *y = final_layer ? p.y : out;
-    const int64_t y_ld = final_layer ? pitch4(query->C) : query->C;  // (y is internal when a final layer follows)
+    const int64_t y_ld = final_layer ? pitch4(q_c) : q_c;  // (y is internal when a final layer follows)
     // (with a final Linear the cross-attend's result is only ever its operand: fc2 writes it as 16-bit rows directly --
     //  env PIO_DEC_Y16=0: the fp32 rows + cast pass of rounds 1-3, for A/B)
     static const bool y16_direct = [] {
         const char *e = getenv("PIO_DEC_Y16");
         return !e || atoi(e) != 0;
     }();
-    const bool direct = final_layer && y16_direct && final_layer->k == padc(query->C);
+    const bool direct = final_layer && y16_direct && final_layer->k == padc(q_c);
     PIO_TRY(cross_attention_run(*cross, *query, *latents, nullptr, query_mask, nullptr, nullptr, y, nullptr, p.cp,
-                                s, nullptr, y_ld, qc, direct ? &p.y16 : nullptr));
+                                s, nullptr, y_ld, qc, direct ? &p.y16 : nullptr, query_tail));
     if (!final_layer) return PIO_OK;
     // perceiver.py:178-179: final nn.Linear on every query row
-    if (final_layer->k != padc(query->C)) return PIO_E_SHAPE;
-    const pio_tensor3_t ty = {y, (int64_t)Q * y_ld, y_ld, B, Q, query->C};
-    if (!direct) PIO_TRY(cast_pair(ty, nullptr, p.y16, padc(query->C), cross->attn.dtype, s));
+    if (final_layer->k != padc(q_c)) return PIO_E_SHAPE;
+    const pio_tensor3_t ty = {y, (int64_t)Q * y_ld, y_ld, B, Q, q_c};
+    if (!direct) PIO_TRY(cast_pair(ty, nullptr, p.y16, padc(q_c), cross->attn.dtype, s));
     return linear_fwd(*final_layer, cross->attn.dtype, p.y16, (int64_t)B * Q, out, nullptr, true, final_out, final_out,
                       0, nullptr, s);
+}
+
+int pio_decoder_fwd_qcache(const pio_cross_attention_t *cross, const pio_linear_t *final_layer, int32_t final_out,
+                           const pio_tensor3_t *query, const pio_tensor3_t *latents, const uint8_t *query_mask,
+                           float *out, void *workspace, size_t workspace_bytes, void *stream, void *q16_hi,
+                           void *q16_lo, int32_t q16_valid) {
+    return decoder_run(cross, final_layer, final_out, query, nullptr, latents, query_mask, out, workspace,
+                       workspace_bytes, stream, q16_hi, q16_lo, q16_valid);
+}
+
+int pio_decoder_fwd_split(const pio_cross_attention_t *cross, const pio_linear_t *final_layer, int32_t final_out,
+                          const pio_tensor3_t *query, const pio_tensor3_t *query_tail, const pio_tensor3_t *latents,
+                          const uint8_t *query_mask, float *out, void *workspace, size_t workspace_bytes, void *stream) {
+    if (!query_tail) return PIO_E_ARG;
+    return decoder_run(cross, final_layer, final_out, query, query_tail, latents, query_mask, out, workspace,
+                       workspace_bytes, stream, nullptr, nullptr, 0);
 }
 
 }  // extern "C"

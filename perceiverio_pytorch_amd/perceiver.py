@@ -234,13 +234,28 @@ class PerceiverDecoder(nn.Module):
         depends on parameters and constants only (MultiModalPerceiver's per-chunk queries).  The decoder leaves the
         normalised + projected queries there on the first call and skips LayerNorm_q / proj_q afterwards
         (pio_decoder_fwd_qcache); it revalidates the entry against its own parameters and the precision policy.  Only
+        without the query residual.
+
+        Extension (as PerceiverEncoder.forward's): `query` may be a pair (features [B,Q,C1], table [Q,C2] or [1,Q,C2])
+        standing for their channel-wise concatenation -- dense decoders whose queries are the network's preprocessed
+        input (FlowQuery): LayerNorm_q reads the two arrays, nothing is concatenated (pio_decoder_fwd_split).  Only
         without the query residual."""
+        query_tail = None
+        if isinstance(query, (tuple, list)):
+            query, query_tail = query
+            if self._use_query_residual:
+                raise ValueError("a (features, table) query needs use_query_residual=False")
         if R.cpu_plumbing(query, "PerceiverDecoder.forward"):
             from . import cpu_plumbing as CP
+            if query_tail is not None:
+                t = query_tail if query_tail.dim() == 3 else query_tail[None]
+                query = torch.cat([query, t.expand(query.shape[0], -1, -1)], dim=-1)
             return CP.decoder(self, query, latents, query_mask)
         R.require_device(query, "PerceiverDecoder.forward")
         lib = L.lib()
         q, z = R.as_f32_3d(query), R.as_f32_3d(latents)
+        if query_tail is not None:
+            query_tail = R.as_f32_3d(query_tail if query_tail.dim() == 3 else query_tail[None])
         B, Q, _ = q.shape
         N = z.shape[1]
         dev = q.device
@@ -253,7 +268,7 @@ class PerceiverDecoder(nn.Module):
         ws = R.workspace(dev, lib.pio_decoder_workspace_bytes(cross, fin_ptr, B, Q, N))
         qhi = qlo = None
         valid = 0
-        if q_cache is not None and not self._use_query_residual:
+        if q_cache is not None and not self._use_query_residual and query_tail is None:
             ca = self.decoding_cross_attn
             Bq = 1 if (q.stride(0) == 0 and B > 1) else B
             try:
@@ -275,9 +290,14 @@ class PerceiverDecoder(nn.Module):
                 qlo = q_cache["lo"].data_ptr() if q_cache["lo"] is not None else None
                 valid = 1 if q_cache["valid"] else 0
         with R.on_device(dev):
-            L.check(lib.pio_decoder_fwd_qcache(cross, fin_ptr, out_ch, R.tensor3(q), R.tensor3(z), qm_ptr, out.data_ptr(),
-                                               ws.data_ptr(), ws.numel(), R.stream_ptr(dev), qhi, qlo, valid),
-                    "pio_decoder_fwd")
+            if query_tail is not None:
+                L.check(lib.pio_decoder_fwd_split(cross, fin_ptr, out_ch, R.tensor3(q), R.tensor3(query_tail), R.tensor3(z),
+                                                  qm_ptr, out.data_ptr(), ws.data_ptr(), ws.numel(), R.stream_ptr(dev)),
+                        "pio_decoder_fwd_split")
+            else:
+                L.check(lib.pio_decoder_fwd_qcache(cross, fin_ptr, out_ch, R.tensor3(q), R.tensor3(z), qm_ptr,
+                                                   out.data_ptr(), ws.data_ptr(), ws.numel(), R.stream_ptr(dev), qhi, qlo,
+                                                   valid), "pio_decoder_fwd")
         if qhi is not None:
             q_cache["valid"] = True
         return R.forward_only(out, query, latents, *self.parameters())
@@ -435,8 +455,23 @@ class PerceiverIO(nn.Module):
         if not hasattr(prep, "forward_split") or not inputs["__default"].is_cuda:
             return None
         if any(getattr(q, "_concat_preprocessed_input", False) for q in self._output_queries.values()):
-            return None
+            # a query that reads the preprocessed inputs needs the concatenated array -- unless the inputs themselves ARE
+            # the query rows (FlowQuery: no position encoding of its own) and the decoder can take them as two arrays too
+            if not self._identity_query():
+                return None
         return prep.forward_split(inputs["__default"])
+
+    def _identity_query(self):
+        """True when the single output query returns the preprocessed inputs unchanged (BasicQuery with
+        PosEncodingType.NONE: output_queries.py) and the decoder neither adds the query back nor pads / sub-samples it:
+        the decoder then takes the encoder's (features, table) pair as its query (PerceiverDecoder.forward)."""
+        qs = list(self._output_queries.values())
+        if len(qs) != 1 or list(self._output_queries.keys()) != ["__default"]:
+            return False
+        q = qs[0]
+        return (getattr(q, "_position_encoding", 0) is None and getattr(q, "_concat_preprocessed_input", False)
+                and not self._decoder._use_query_residual and self.decoder_query_rows is None
+                and q.n_query_channels() == self.query_channels)
 
     def decoder_query(self, inputs, modality_sizes, inputs_without_pos=None, subsampled_points=None):
         per_mod = restructure(modality_sizes, inputs)
@@ -498,8 +533,16 @@ class PerceiverIO(nn.Module):
             feats, table = split[1], split[2]
             sizes, without_pos = {"__default": feats.shape[1]}, {"__default": feats}
             latents0 = self._encoder.latents(feats)
-            query, query_sizes = self.decoder_query(feats, sizes, without_pos,
-                                                    subsampled_points=subsampled_output_points)
+            if self._identity_query() and subsampled_output_points is None and query_shard is None:
+                query, query_sizes = (feats, table), dict(sizes)      # the inputs are the query rows: two arrays again
+            else:
+                if self._identity_query():
+                    x = torch.cat([feats, torch.broadcast_to(table[None], (feats.shape[0],) + tuple(table.shape))], -1)
+                    query, query_sizes = self.decoder_query(x, sizes, without_pos,
+                                                            subsampled_points=subsampled_output_points)
+                else:
+                    query, query_sizes = self.decoder_query(feats, sizes, without_pos,
+                                                            subsampled_points=subsampled_output_points)
             with R.precision(self.encoder_policy):
                 latents = self._encoder((feats, table), latents0, input_mask=input_mask)
         else:

@@ -347,3 +347,28 @@ def test_split_encoder_input_is_bit_identical_to_the_concatenated_one():
         y_cat = model(x)
     assert torch.equal(y_split, y_cat)
     _close(y_split, g["out"], "split encoder input vs golden", TOL)
+
+
+@pytest.mark.gpu
+def test_flow_inputs_reach_encoder_and_decoder_as_two_arrays():
+    """FlowPerceiver: the preprocessed inputs are [64 conv-after-patches features | one 258-channel Fourier table] and ARE the
+    decoder's query rows (FlowQuery).  Encoder (pio_encoder_fwd_split) and decoder (pio_decoder_fwd_split: LayerNorm_q over
+    the two arrays) both take the pair -- the [1, 182 528, 322] fp32 array is never built -- and give the flow field of the
+    materialised hand-off bit for bit, and the reference golden within 1e-3."""
+    dev = torch.device("cuda:0")
+    name = "model_flow_full"
+    g = load(name)
+    model = _load_generated(build(name), g, dev, model_seed(name), model_stats(name))
+    ins = [torch.from_numpy(a).to(dev) for a in model_inputs(name)]
+    io = model.perceiver
+    assert io.split_encoder_input and io._identity_query()
+    calls = []
+    dec_fwd = io._decoder.forward
+    io._decoder.forward = lambda q, *a, **k: (calls.append(type(q)), dec_fwd(q, *a, **k))[1]
+    with torch.inference_mode():
+        y_split = model(ins[0], ins[1])
+        io.split_encoder_input = False
+        y_cat = model(ins[0], ins[1])
+    assert calls == [tuple, torch.Tensor], calls
+    assert torch.equal(y_split, y_cat)
+    _close(y_split[:, :, ::8, ::8], g["out_sub"], "flow, inputs as two arrays", TOL, absmax=g["out_absmax"])

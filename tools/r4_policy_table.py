@@ -36,6 +36,9 @@ for pol in sys.argv[2:]:
             torch.cuda.synchronize()
             ms = f" {e0.elapsed_time(e1) / n:7.3f} ms eager"
         del inputs
+    kl = r.get("known_limit")
+    if kl:
+        cells += f"  | trained-like (known limit): {kl['relL2']*1e4:.1f}/{kl['max_abs_over_absmax']*1e4:.1f}"
     print(f"{pol:28s}{ms} worst relL2 {r['relL2']:.2e} max {r['max_abs_over_absmax']:.2e} ok={r['ok']} | x1e-4: {cells}", flush=True)
     del model
     torch.cuda.empty_cache()
