@@ -154,6 +154,40 @@ __global__ __launch_bounds__(256 * KG) void gemm_nt_128(const GemmParams p) {
 #pragma unroll
     for (int i = 0; i < NI; ++i) b_off[i] = (wn * (TN / 2) + i * 16 + frow) * 128;
 
+    // Epilogue operands fetched HERE, ahead of the ring (older than every DMA piece: the counted waits still hold): the
+    // bias / LayerNorm-fold column constants of this thread's four columns and, for the fold's consumer, the row's partial
+    // sums -- on the small tiles their round trips (two dependent ones: statistics -> barrier -> constants) were ~1.5 us of
+    // a ~9 us launch, exposed behind the last K step.
+    constexpr int CPR_ = TN / 4;
+    const int pre_n0 = tile_n * TN + (tid & (CPR_ - 1)) * 4;
+    f32x4 bias_pre = {0.f, 0.f, 0.f, 0.f}, lnc_pre = {0.f, 0.f, 0.f, 0.f};
+    constexpr int MAXS = 24;                     // statistics slots held in registers (K <= 1536 in 64-column slots)
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 part_pre[MAXS];
+    // (branch-free: whole 16-byte loads of interior columns, slot indices clamped -- a conditional load costs a branch and
+    //  a drained vmcnt each; edge tiles and unaligned operands fetch in the epilogue as before)
+    // (only the 32 x 64 tile: same-box A/B of the ImageNet forward, graph replay, B = 1 2.940 -> 2.899 ms; with it on the
+    //  64 x 64 tile B = 4 4.66 -> 4.73, B = 8 7.20 -> 7.23 -- two workgroups per CU cover each other's epilogue, the 48
+    //  registers only cost)
+    constexpr bool PRE = TM == 32;
+    const bool pre_cols = PRE && tid < 256 && pre_n0 + 3 < p.N && (p.bias_mode != 1 || p.bias_vec) &&
+                          (!p.ln_part || ((uintptr_t)p.ln_c & 15) == 0);
+    const bool pre_stat = PRE && p.ln_part && p.ln_slots <= MAXS && ((uintptr_t)p.ln_part & 7) == 0;
+    if (pre_cols) {
+        if (p.bias_mode == 1) bias_pre = *(const f32x4 *)(p.bias + pre_n0);
+        if (p.ln_part) lnc_pre = *(const f32x4 *)(p.ln_c + pre_n0);
+    }
+    if (pre_stat && tid < TM) {
+        int m = tile_m * TM + tid;
+        m = m < p.M ? m : p.M - 1;
+        const f32x2 *pr = (const f32x2 *)(p.ln_part + (int64_t)m * p.ln_slots * 2);
+        const int last = p.ln_slots - 1;
+#pragma unroll
+        for (int i = 0; i < MAXS; ++i) part_pre[i] = pr[i < last ? i : last];
+    }
+    // (nothing of the above may sink below a DMA piece: a younger plain load would shift the window of the counted waits)
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
     if constexpr (NS == 2) stage(0, 0);
     else {
         // ring prologue: steps 0 .. NS-2 in flight (a step past the end repeats step 0's valid sources: the counts stay
@@ -237,9 +271,17 @@ __global__ __launch_bounds__(256 * KG) void gemm_nt_128(const GemmParams p) {
         m = m < p.M ? m : p.M - 1;
         const float *pr = p.ln_part + (int64_t)m * p.ln_slots * 2;
         float sm = 0.f, sq = 0.f;
-        for (int i = 0; i < p.ln_slots; ++i) {
-            sm += pr[2 * i];
-            sq += pr[2 * i + 1];
+        if (pre_stat) {
+#pragma unroll
+            for (int i = 0; i < MAXS; ++i) {     // (same order of additions as the loop below)
+                sm += i < p.ln_slots ? part_pre[i][0] : 0.f;
+                sq += i < p.ln_slots ? part_pre[i][1] : 0.f;
+            }
+        } else {
+            for (int i = 0; i < p.ln_slots; ++i) {
+                sm += pr[2 * i];
+                sq += pr[2 * i + 1];
+            }
         }
         const float mean = sm * p.ln_inv_k;
         float var = sq * p.ln_inv_k - mean * mean;
@@ -257,21 +299,18 @@ __global__ __launch_bounds__(256 * KG) void gemm_nt_128(const GemmParams p) {
     const int n0 = tile_n * TN + c * 4;
     if (n0 < p.n_store) {
         const bool nfull = n0 + 3 < p.N;
-        f32x4 bias_n = {0.f, 0.f, 0.f, 0.f};
-        if (p.bias_mode == 1) {
-            if (nfull && p.bias_vec) {
-                bias_n = *(const f32x4 *)(p.bias + n0);
-            } else {
+        f32x4 bias_n = bias_pre, lnc = lnc_pre;   // (fetched ahead of the K loop ...
+        if (!pre_cols) {                          //  ... except on edge tiles / unaligned operands)
+            if (p.bias_mode == 1) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     if (n0 + r < p.N) bias_n[r] = p.bias[n0 + r];
             }
-        }
-        f32x4 lnc = {0.f, 0.f, 0.f, 0.f};
-        if (p.ln_part) {
+            if (p.ln_part) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (n0 + r < p.N) lnc[r] = p.ln_c[n0 + r];
+                for (int r = 0; r < 4; ++r)
+                    if (n0 + r < p.N) lnc[r] = p.ln_c[n0 + r];
+            }
         }
 #pragma unroll 4
         for (int it = 0; it < TM / RPI; ++it) {
