@@ -436,6 +436,66 @@ extern "C" int pio_debug_g128_stamps(unsigned long long *out128, int block) {
 }
 #endif
 
+// C[M, n_store <= NMAX] = A B^T for a handful of output columns (the flow decoder's final Linear: 182 528 x 328 -> 2; on
+// a 128 x 128 tile 98 % of the MFMAs multiply padding: 234 us for a read of 240 MB).  No matrix pipe: a wave takes one row
+// at a time, lane j the 16-byte chunk j of that row (of every K sweep's A image), multiplies it with the same chunk of the
+// NMAX weight rows (LDS) in fp32, and the 64 lanes are summed by xor-shuffles.  Bound by the read of A.
+template <int DT, int NMAX>
+__global__ __launch_bounds__(256) void gemm_nt_skinny(const GemmParams p) {
+    typedef typename Op<DT>::T T;
+    typedef typename Op<DT>::V8 V8;
+    extern __shared__ __attribute__((aligned(16))) char sk_smem[];   // [npass][NMAX][K] weight rows (zeros past N)
+    T *const bs = (T *)sk_smem;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int K = p.K, cpr = K >> 3;   // 16-byte chunks per row (K % 8 == 0: launcher)
+    for (int i = tid; i < p.npass * NMAX * cpr; i += 256) {
+        const int pass = i / (NMAX * cpr), r = i - pass * NMAX * cpr;
+        const int n = r / cpr, c = r - n * cpr;
+        const int64_t dB = pass == 0 ? 0 : (pass == 1 ? p.dB1 : p.dB2);
+        V8 w;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) w[e] = Op<DT>::from_f32(0.f);
+        if (n < p.N) w = *(const V8 *)((const T *)p.B + dB + (int64_t)n * p.ldb + c * 8);
+        *(V8 *)(bs + ((int64_t)pass * NMAX + n) * K + c * 8) = w;
+    }
+    __syncthreads();
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + (tid >> 6), nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t m = wave0; m < p.M; m += nwaves) {
+        float acc[NMAX];
+#pragma unroll
+        for (int n = 0; n < NMAX; ++n) acc[n] = 0.f;
+        for (int c = lane; c < cpr; c += 64) {
+            for (int pass = 0; pass < p.npass; ++pass) {
+                const int64_t dA = pass == 0 ? 0 : (pass == 1 ? p.dA1 : p.dA2);
+                const V8 a = *(const V8 *)((const T *)p.A + dA + m * p.lda + c * 8);
+                float af[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) af[e] = Op<DT>::to_f32(a[e]);
+#pragma unroll
+                for (int n = 0; n < NMAX; ++n) {
+                    const V8 w = *(const V8 *)(bs + ((int64_t)pass * NMAX + n) * K + c * 8);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[n] = fmaf(af[e], Op<DT>::to_f32(w[e]), acc[n]);
+                }
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < NMAX; ++n)
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) acc[n] += __shfl_xor(acc[n], o, 64);
+        if (lane < p.n_store) {
+            float x = 0.f;
+#pragma unroll
+            for (int n = 0; n < NMAX; ++n)
+                if (n == lane) x = acc[n];
+            x = x * p.alpha + ((p.bias_mode == 1 && lane < p.N) ? p.bias[lane] : 0.f);
+            if (lane >= p.N) x = 0.f;   // columns [N, n_store) are written as zeros
+            if (p.out_f32) ((float *)p.C)[m * p.ldc + lane] = x;
+            else ((T *)p.C)[m * p.ldc + lane] = Op<DT>::from_f32(x);
+        }
+    }
+}
+
 // kernel selection override (pio_gemm_kernel_override; initial value from env PIO_GEMM_TILE)
 static int &gemm_kernel_choice() {
     static int choice = [] {
@@ -562,6 +622,34 @@ int gemm_nt_launch(const pio_gemm_t &g, hipStream_t s) {
     if (g.R16_hi) algo_bytes += 4.0 * mn;
     else if (g.R) algo_bytes += 4.0 * mn;
     if (g.ln_part) algo_bytes += 64.0 * g.M;
+    // A handful of output columns over many rows: no tile kernel (see gemm_nt_skinny); env PIO_GEMM_SKINNY=0: A/B switch
+    {
+        static const bool skinny_on = [] {
+            const char *e = getenv("PIO_GEMM_SKINNY");
+            return !e || atoi(e) != 0;
+        }();
+        const bool plain = !p.X16 && !p.row_part && !p.ln_part && !p.ln_c && !p.X16_lo && !p.R16_hi && !p.R16_lo && !p.R &&
+                           !p.C_lo && g.act == 0 && g.bias_mode <= 1 && !g.b_lo_n0 && g.C;
+        // (up to four columns: 182 528 x 328 -> 2 with split activations 50 us against 70 on the 128 x 128 tile; at eight
+        //  columns x K = 1032 the fp32 FMAs of this kernel cost more than the tile's padding: 190 against 125 us)
+        if (skinny_on && gemm_kernel_choice() == 0 && plain && g.batch == 1 && p.n_store <= 4 && g.M >= 2048 &&
+            g.K <= 2048 && p.n_store <= g.ldc) {
+            ProfScope prof(PROF_GEMM_SMALL, algo_flops, algo_bytes, s);
+            gemm_log("skinny", g, p);
+            const int nmax = p.n_store <= 2 ? 2 : 4;
+            const size_t lds = (size_t)p.npass * nmax * g.K * 2;   // <= 48 KiB
+            const unsigned blocks = (unsigned)(g.M / 4 < 256 * 8 ? (g.M + 3) / 4 : 256 * 8);
+#define PIO_SK(DTV)                                                                                                  \
+    do {                                                                                                             \
+        if (nmax == 2) hipLaunchKernelGGL((gemm_nt_skinny<DTV, 2>), dim3(blocks), dim3(256), lds, s, p);             \
+        else hipLaunchKernelGGL((gemm_nt_skinny<DTV, 4>), dim3(blocks), dim3(256), lds, s, p);                       \
+    } while (0)
+            if (g.dtype == PIO_DT_F16) PIO_SK(PIO_DT_F16);
+            else PIO_SK(PIO_DT_BF16);
+#undef PIO_SK
+            return launch_status();
+        }
+    }
     // Large problems go to the 256x256-tile / 4-slot-ring kernel: enough rows, and an N that fills whole
     // 256-column tiles reasonably (<= 25 % padding).  PIO_GEMM_TILE=128|256 forces one (benchmarks).
     {

@@ -83,6 +83,62 @@ GEMM_SHAPES = [
 ]
 
 
+SKINNY_SHAPES = [
+    # M, N, n_store, ldc, K, out_f32, a_lo, b_lo     (M >= 2048, n_store <= 4: gemm_nt_skinny)
+    (182528 // 8, 2, 2, 2, 328, True, True, False),      # the flow decoder's final Linear (rows / 8), split activations
+    (5000, 2, 2, 2, 328, True, True, True),              # + split weights (three K sweeps)
+    (4099, 3, 4, 8, 1032, False, False, False),          # 16-bit out, pad column 3 written as zero, ldc > n_store, ragged M
+    (2048, 4, 4, 4, 72, True, False, True),              # short K
+    (3000, 1, 1, 1, 2048, True, True, False),            # one column; K = 2048: four chunks per lane
+]
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("shape", SKINNY_SHAPES)
+def test_gemm_nt_few_output_columns(dev, shape, dt):
+    """Many rows x a handful of output columns (decoder final Linears with 2-8 outputs): pio_gemm_nt routes them to the
+    row-per-wave kernel instead of a 128 x 128 tile; every K sweep (A_lo, B_lo), the bias, alpha, pad columns and the
+    output forms against float64."""
+    from perceiverio_pytorch_amd import _lib as L
+    lib = L.lib()
+    M, N, n_store, ldc, K, out_f32, a_lo, b_lo = shape
+    tdt = torch.float16 if dt == "f16" else torch.bfloat16
+    g = torch.Generator(device="cpu").manual_seed(M + 13 * N + K)
+    Af = torch.randn(M, K, generator=g) * 3.0
+    Ahi = Af.to(tdt)
+    Alo = (Af - Ahi.float()).to(tdt)
+    Bf = torch.randn(N, K, generator=g) / K ** 0.5
+    Bhi = Bf.to(tdt)
+    Blo = (Bf - Bhi.float()).to(tdt)
+    bias = torch.randn(N, generator=g)
+    Cout = torch.full((M, ldc), float("nan"), dtype=torch.float32 if out_f32 else tdt)
+    Ad, Ald, Bd, Bld, bd, Cd = (x.to(dev) for x in (Ahi, Alo, Bhi, Blo, bias, Cout))
+    gm = L.Gemm()
+    gm.A, gm.B, gm.C = Ad.data_ptr(), Bd.data_ptr(), Cd.data_ptr()
+    gm.A_lo = Ald.data_ptr() if a_lo else None
+    gm.B_lo = Bld.data_ptr() if b_lo else None
+    gm.M, gm.N, gm.K = M, N, K
+    gm.lda, gm.ldb, gm.ldc = K, K, ldc
+    gm.batch, gm.nh = 1, 1
+    gm.bias, gm.bias_mode, gm.act, gm.alpha = bd.data_ptr(), 1, 0, 0.75
+    gm.out_f32, gm.n_store = int(out_f32), n_store
+    gm.dtype = L.PIO_DT_F16 if dt == "f16" else L.PIO_DT_BF16
+    L.check(lib.pio_gemm_nt(C.byref(gm), torch.cuda.current_stream().cuda_stream), "pio_gemm_nt")
+    torch.cuda.synchronize()
+    Aop = Ahi.double() + (Alo.double() if a_lo else 0)
+    Bop = Bhi.double() + (Blo.double() if b_lo else 0)
+    ref = 0.75 * (Aop @ Bop.T) + bias.double()[None, :]
+    if a_lo and b_lo:
+        ref = ref - 0.75 * (Alo.double() @ Blo.double().T)     # (the dropped lo x lo term)
+    got = Cd.float().cpu().double()
+    assert torch.isfinite(got[:, :n_store]).all()
+    assert (got[:, N:n_store] == 0).all(), "pad columns must be written as zeros"
+    assert torch.isnan(got[:, n_store:]).all(), "columns past n_store must not be touched"
+    tol = 2e-5 if out_f32 else (1e-3 if dt == "f16" else 8e-3)
+    err = (got[:, :N] - ref).abs().max() / ref.abs().max()
+    assert err <= tol, f"skinny gemm {shape} {dt}: {err:.3e}"
+
+
 @pytest.mark.parametrize("dt", ["f16", "bf16"])
 @pytest.mark.parametrize("shape", GEMM_SHAPES)
 def test_gemm_nt(dev, shape, dt):
