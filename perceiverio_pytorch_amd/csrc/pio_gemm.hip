@@ -788,9 +788,14 @@ int gemm_nt_launch(const pio_gemm_t &g, hipStream_t s) {
     //  ImageNet B = 1 gains 5.6 %: tools/ab_env.py)
     const bool kg2 = small && kg2_on && gemm_kernel_choice() == 0 && p.npass * g.K >= 1024 &&
                      (int64_t)grid.x * grid.y <= (int64_t)cu_budget();
+    // ... and the 128 x 128 tile likewise when it owns its CU alone (ImageNet B = 2: the 1024 x 3072 x 1024 q|k|v GEMM has
+    // 192 tiles; forward 4.62 -> 4.46 ms, tools/ab_env.py)
+    const bool kg2_128 = !small && !ring128 && kg2_on && gemm_kernel_choice() == 0 && p.npass * g.K >= 1024 &&
+                         (int64_t)grid.x * grid.y <= (int64_t)cu_budget();
 #define PIO_G128(DTV, KINDV)                                                                            \
     do {                                                                                                \
-        if (tiny && kg2) hipLaunchKernelGGL((gemm_nt_128<DTV, KINDV, 32, 64, 4, 2>), grid, dim3(512, 1, 1), 0, s, p); \
+        if (kg2_128) hipLaunchKernelGGL((gemm_nt_128<DTV, KINDV, 128, 128, 2, 2>), grid, dim3(512, 1, 1), 0, s, p); \
+        else if (tiny && kg2) hipLaunchKernelGGL((gemm_nt_128<DTV, KINDV, 32, 64, 4, 2>), grid, dim3(512, 1, 1), 0, s, p); \
         else if (small && kg2) hipLaunchKernelGGL((gemm_nt_128<DTV, KINDV, 64, 64, 4, 2>), grid, dim3(512, 1, 1), 0, s, p); \
         else if (tiny) hipLaunchKernelGGL((gemm_nt_128<DTV, KINDV, 32, 64, 4>), grid, block, 0, s, p);  \
         else if (small) hipLaunchKernelGGL((gemm_nt_128<DTV, KINDV, 64, 64, 4>), grid, block, 0, s, p); \
