@@ -80,6 +80,11 @@ GEMM_SHAPES = [
     (1030, 1000, 72, 1, 1, 1, 0, True, True, True),       # fp32 ldc=1000, residual, two-pass weights, K=72
     (1024, 256, 40, 2, 1, 2, 0, False, True, False),      # batched, per-row bias, K < one ring (2 K tiles)
     (4096, 512, 1024, 1, 1, 1, 0, False, False, False),
+    # tiles that own their CU alone run as two K teams of four waves (KG = 2: DESIGN_LOG R4.11)
+    (1024, 1024, 1024, 1, 1, 1, 1, False, False, False),  # 256 tiles of 64 x 64, GELU, 16-bit out
+    (1000, 1000, 1096, 1, 1, 1, 0, True, True, True),     # ... ragged M / N / K, residual, two-pass weights
+    (1024, 3072, 1024, 1, 1, 1, 0, False, False, False),  # 192 tiles of 128 x 128 (the B = 2 q|k|v projection)
+    (512, 1024, 2048, 1, 1, 1, 0, True, True, False),     # 256 tiles of 32 x 64, K = 2048
 ]
 
 
