@@ -71,8 +71,8 @@ from .position_encoding import PosEncodingType
 #    KNOWN LIMIT (tests/golden/model_language_trained): with trained-like statistics (LayerNorm gains up to 5) the
 #    attention logits of this model reach |s| ~ 10-15, and q / k rounded ONCE to fp16 in front of the fused cores put
 #    delta s ~ |s| 2^-11 into the exponent: 2.6e-3 / 4.1e-3 under every policy with fused single-sweep cores in the
-#    cross-attends (the latent stack's cores alone: 7.3e-4 / 8.7e-4); only "fp16x3" (materialised fp32 scores, 1e-5)
-#    holds there.  Fix not built: Q / K as 16-bit pairs in the cores' Q K^T (three MFMAs instead of one on 1/6 of the
+#    cross-attends (the latent stack's cores alone -- "fp16x3/fp16x3f/fp16x3", 50 ms -- 7.1e-4 / 8.7e-4 ... 1.03e-3 by
+#    rounding realisation); only "fp16x3" (materialised fp32 scores, 1e-5, 59 ms) holds there.  Fix not built: Q / K as 16-bit pairs in the cores' Q K^T (three MFMAs instead of one on 1/6 of the
 #    core's flops for 32-wide heads).
 DEFAULT_POLICY = {"ClassificationPerceiver": "fp16x2w/fp16sd/fp16x2af", "LanguagePerceiver": "fp16x2w/fp16x2o/fp16x3f",
                   "FlowPerceiver": "fp16/fp16x2af", "MultiModalPerceiver": "fp16x2w/fp16x2afo"}
