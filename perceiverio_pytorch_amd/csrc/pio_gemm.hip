@@ -468,14 +468,26 @@ __global__ __launch_bounds__(256) void gemm_nt_skinny(const GemmParams p) {
             for (int pass = 0; pass < p.npass; ++pass) {
                 const int64_t dA = pass == 0 ? 0 : (pass == 1 ? p.dA1 : p.dA2);
                 const V8 a = *(const V8 *)((const T *)p.A + dA + m * p.lda + c * 8);
-                float af[8];
+                if constexpr (DT == PIO_DT_F16) {
+                    // v_dot2_f32_f16: two products and the sum in fp32 per instruction
+                    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-                for (int e = 0; e < 8; ++e) af[e] = Op<DT>::to_f32(a[e]);
+                    for (int n = 0; n < NMAX; ++n) {
+                        const V8 w = *(const V8 *)(bs + ((int64_t)pass * NMAX + n) * K + c * 8);
 #pragma unroll
-                for (int n = 0; n < NMAX; ++n) {
-                    const V8 w = *(const V8 *)(bs + ((int64_t)pass * NMAX + n) * K + c * 8);
+                        for (int e = 0; e < 8; e += 2)
+                            acc[n] = __builtin_amdgcn_fdot2(h2{a[e], a[e + 1]}, h2{w[e], w[e + 1]}, acc[n], false);
+                    }
+                } else {
+                    float af[8];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) acc[n] = fmaf(af[e], Op<DT>::to_f32(w[e]), acc[n]);
+                    for (int e = 0; e < 8; ++e) af[e] = Op<DT>::to_f32(a[e]);
+#pragma unroll
+                    for (int n = 0; n < NMAX; ++n) {
+                        const V8 w = *(const V8 *)(bs + ((int64_t)pass * NMAX + n) * K + c * 8);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) acc[n] = fmaf(af[e], Op<DT>::to_f32(w[e]), acc[n]);
+                    }
                 }
             }
         }
@@ -630,7 +642,7 @@ int gemm_nt_launch(const pio_gemm_t &g, hipStream_t s) {
         }();
         const bool plain = !p.X16 && !p.row_part && !p.ln_part && !p.ln_c && !p.X16_lo && !p.R16_hi && !p.R16_lo && !p.R &&
                            !p.C_lo && g.act == 0 && g.bias_mode <= 1 && !g.b_lo_n0 && g.C;
-        // (up to four columns: 182 528 x 328 -> 2 with split activations 50 us against 70 on the 128 x 128 tile; at eight
+        // (up to four columns: 182 528 x 328 -> 2 with split activations 42 us against 70 on the 128 x 128 tile; at eight
         //  columns x K = 1032 the fp32 FMAs of this kernel cost more than the tile's padding: 190 against 125 us)
         if (skinny_on && gemm_kernel_choice() == 0 && plain && g.batch == 1 && p.n_store <= 4 && g.M >= 2048 &&
             g.K <= 2048 && p.n_store <= g.ldc) {

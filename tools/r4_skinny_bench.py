@@ -41,4 +41,4 @@ def run(M, N, K, a_lo, iters=50):
 
 run(182528, 2, 328, True)
 run(182528, 2, 328, False)
-run(104192, 8, 1032, True)
+run(100352, 3, 512, True)
