@@ -72,8 +72,11 @@ from .position_encoding import PosEncodingType
 #    attention logits of this model reach |s| ~ 10-15, and q / k rounded ONCE to fp16 in front of the fused cores put
 #    delta s ~ |s| 2^-11 into the exponent: 2.6e-3 / 4.1e-3 under every policy with fused single-sweep cores in the
 #    cross-attends (the latent stack's cores alone -- "fp16x3/fp16x3f/fp16x3", 50 ms -- 7.1e-4 / 8.7e-4 ... 1.03e-3 by
-#    rounding realisation); only "fp16x3" (materialised fp32 scores, 1e-5, 59 ms) holds there.  Fix not built: Q / K as 16-bit pairs in the cores' Q K^T (three MFMAs instead of one on 1/6 of the
-#    core's flops for 32-wide heads).
+#    rounding realisation); only "fp16x3" (materialised fp32 scores, 1e-5, 59 ms) holds there.  Q / K as 16-bit pairs in
+#    the cores' Q K^T (three MFMAs instead of one on 1/6 of a 32-wide head's flops; not built) would remove the cores'
+#    share, but on that golden the stack's GEMMs alone leave 8e-4 ... 1e-3 under "x2w" / "x2s" (exact cross-attends,
+#    "fp16x3/fp16x2w/fp16x3f": 1.09e-3 / 1.44e-3; "fp16x3/fp16x2s/fp16x3": 1.20e-3 / 1.34e-3): with those statistics this
+#    model needs three-sweep GEMMs AND pair cores, i.e. about twice the default's time.
 DEFAULT_POLICY = {"ClassificationPerceiver": "fp16x2w/fp16sd/fp16x2af", "LanguagePerceiver": "fp16x2w/fp16x2o/fp16x3f",
                   "FlowPerceiver": "fp16/fp16x2af", "MultiModalPerceiver": "fp16x2w/fp16x2afo"}
 
