@@ -198,7 +198,12 @@ __global__ __launch_bounds__(256) void gemm_nt_wide(const GemmParams p, int tile
     // rounding residual of the weights) the tiles whose columns have one run the K range twice, the second time
     // against B_lo -- same A slices, same accumulators.  Columns below p.lo_n0 (a multiple of 256) have no B_lo.
     const int nphK = p.K / W_BK;
-    auto nph_of = [&](int tn) { return (p.npass == 2 && tn * W_BN >= p.lo_n0) ? 2 * nphK : nphK; };
+    // (p.npass sweeps in general -- (A, B) [, (A, B_lo)] [, (A_lo, B)]: split activations and / or split weights -- each at
+    //  its operand offsets dA / dB; only the B_lo-only form knows columns without a second image)
+    auto nph_of = [&](int tn) {
+        if (p.npass == 2 && p.dA1 == 0) return tn * W_BN >= p.lo_n0 ? 2 * nphK : nphK;
+        return p.npass * nphK;
+    };
 
     // ---- DMA side: a 1-KiB piece = 16 rows x 64 B; wave w owns A pieces 4w..4w+3 and B pieces 4w..4w+3 of a slice.
     const int prow = lane >> 2;
@@ -234,10 +239,11 @@ __global__ __launch_bounds__(256) void gemm_nt_wide(const GemmParams p, int tile
             // in the blocked walk consecutive tiles of a workgroup share their A panel, and the slices a tile used LAST
             // are the ones still in the XCD's L2 when the next tile starts (the panel as a whole is not: a round of
             // 8 x 4 tiles streams 6 MB through a 4 MB L2)
-            const int kph0 = dph < nphK ? dph : dph - nphK;
+            const int sw = (dph >= nphK) + (dph >= 2 * nphK);   // sweep
+            const int kph0 = dph - sw * nphK;
             const int kph = (p.k_rev && (dj & 1)) ? nphK - 1 - kph0 : kph0;
-            ia = (const char *)((const T *)p.A + kph * W_BK);
-            ib = (const char *)((const T *)p.B + (dph < nphK ? 0 : p.dB1) + kph * W_BK);
+            ia = (const char *)((const T *)p.A + (sw == 0 ? 0 : (sw == 1 ? p.dA1 : p.dA2)) + kph * W_BK);
+            ib = (const char *)((const T *)p.B + (sw == 0 ? 0 : (sw == 1 ? p.dB1 : p.dB2)) + kph * W_BK);
             isb = smem + dslot * W_STAGE + wave * 4096;
             istep = 1024;
             ibo = W_AB;
@@ -872,6 +878,8 @@ __global__ __launch_bounds__(256) void gemm_nt_wide(const GemmParams p, int tile
             }
             return x;
         };
+        // (the lo image of a hi + lo result lives at a wave-uniform byte distance from the hi image: no second address)
+        const int64_t lo_delta = (LNF == 0 && p.C_lo) ? (int64_t)((const char *)p.C_lo - (const char *)p.C) : 0;
         if (interior) {
             // interior tile (every column < N <= n_store): one row pointer per mi, the four column groups are
             // immediate offsets of the store
@@ -908,6 +916,17 @@ __global__ __launch_bounds__(256) void gemm_nt_wide(const GemmParams p, int tile
                         h[4 + r] = Op<DT>::from_f32(y1[r]);
                     }
                     *(V8 *)(crow + pp * 64) = h;
+                    if constexpr (LNF == 0) {
+                        if (lo_delta) {   // (uniform) the result's lo image, at a constant distance from the hi one
+                            V8 l;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                l[r] = Op<DT>::from_f32(y0[r] - Op<DT>::to_f32(h[r]));
+                                l[4 + r] = Op<DT>::from_f32(y1[r] - Op<DT>::to_f32(h[4 + r]));
+                            }
+                            *(V8 *)(crow + lo_delta + pp * 64) = l;
+                        }
+                    }
                     __builtin_amdgcn_sched_barrier(0);  // (else all 256 accumulators are read out before the first store)
                 }
                 crow += rstep;
@@ -924,18 +943,25 @@ __global__ __launch_bounds__(256) void gemm_nt_wide(const GemmParams p, int tile
     #pragma unroll
                 for (int mi = 0; mi < 8; ++mi) {
                     const int m = o_m + mi * 16;
-                    V8 h;
+                    V8 h, l;
     #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        h[r] = Op<DT>::from_f32(val(acc_read(acc[mi][2 * pp][r]), b0[r], c0[r], mi));
-                        h[4 + r] = Op<DT>::from_f32(val(acc_read(acc[mi][2 * pp + 1][r]), b1[r], c1[r], mi));
+                        const float y0 = val(acc_read(acc[mi][2 * pp][r]), b0[r], c0[r], mi);
+                        const float y1 = val(acc_read(acc[mi][2 * pp + 1][r]), b1[r], c1[r], mi);
+                        h[r] = Op<DT>::from_f32(y0);
+                        h[4 + r] = Op<DT>::from_f32(y1);
+                        l[r] = Op<DT>::from_f32(y0 - Op<DT>::to_f32(h[r]));
+                        l[4 + r] = Op<DT>::from_f32(y1 - Op<DT>::to_f32(h[4 + r]));
                     }
                     if (n >= p.N) {
     #pragma unroll
-                        for (int r = 0; r < 8; ++r) h[r] = Op<DT>::from_f32(0.f);  // columns [N, n_store): zeros
+                        for (int r = 0; r < 8; ++r) h[r] = l[r] = Op<DT>::from_f32(0.f);  // columns [N, n_store): zeros
                     }
                     const bool ok = m < p.M && n < p.n_store;
                     *(V8 *)(ok ? (char *)(cbase + (int64_t)m * p.ldc + n) : sink) = h;
+                    if constexpr (LNF == 0) {
+                        if (lo_delta) *(V8 *)(ok ? (char *)(cbase + (int64_t)m * p.ldc + n) + lo_delta : sink) = l;
+                    }
                     __builtin_amdgcn_sched_barrier(0);  // (else all 256 accumulators are read out before the first store)
                 }
             }
@@ -973,12 +999,16 @@ static int wide_grid(int64_t total) {
 }
 
 bool gemm_wide_ok(const GemmParams &p, int batch) {
-    if (batch != 1 || p.npass > 2) return false;
-    // a second sweep against B_lo only (weights as hi + lo, single activations), from a 256-aligned column on
-    if (p.npass == 2 && (p.dA1 != 0 || p.dB1 == 0 || p.lo_n0 < 0 || (p.lo_n0 % W_BN))) return false;
-    if (p.npass == 1 && p.lo_n0 != 0) return false;
+    if (batch != 1 || p.npass > 3) return false;
+    // a second sweep against B_lo only (weights as hi + lo, single activations) may start at a 256-aligned column; the
+    // sweeps with an A_lo image (split activations: dA1 or dA2) cover every column
+    const bool b_lo_only = p.npass == 2 && p.dA1 == 0;
+    if (b_lo_only && (p.dB1 == 0 || p.lo_n0 < 0 || (p.lo_n0 % W_BN))) return false;
+    if (!b_lo_only && p.lo_n0 != 0) return false;
     if (p.K < 4 * W_BK || (p.K % (2 * W_BK))) return false;
-    if (p.C_lo || (p.act != 0 && p.act != 1)) return false;
+    if (p.act != 0 && p.act != 1) return false;
+    // the hi + lo pair of the result: the plain 16-bit epilogue only (not the fold forms, not fp32 out)
+    if (p.C_lo && (p.out_f32 || p.ln_part || p.row_part || p.X16 || ((uintptr_t)p.C_lo & 15))) return false;
     if (p.out_f32 && (p.act != 0 || (p.C && (p.ldc & 3)))) return false;
     if (p.R && (!p.out_f32 || !p.r_vec || p.r_rows != 0 || (p.ldr & 3))) return false;
     if (p.X16 || p.row_part || p.X16_lo || p.R16_hi || p.R16_lo) {  // LayerNorm-fold producer

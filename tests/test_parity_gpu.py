@@ -236,6 +236,76 @@ def test_gemm_nt_wide(dev, shape, dt):
     _gemm_case(dev, shape, dt, shape[-1], "wide")
 
 
+WIDE_PAIR_SHAPES = [
+    # M, N, K, act, out_f32, b_lo, c_lo      (A always hi + lo: the dense decoders' split-activation GEMMs)
+    (4096, 1024, 1024, 1, False, False, True),     # decoder fc1: GELU, hi + lo result
+    (3000, 1026, 1088, 1, False, False, True),     # ... at the multimodal decoder's widths: ragged M, N = 4 x 256 + 2
+    (2048, 1024, 512, 0, True, True, False),       # out projection / final Linear under "x2afo": three sweeps, fp32 out
+    (2304, 520, 256, 0, False, True, True),        # three sweeps, hi + lo result, edge tiles
+    (2048, 512, 128, 0, False, False, False),      # two sweeps, one 16-bit result
+]
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("shape", WIDE_PAIR_SHAPES)
+def test_gemm_nt_wide_split_activations(dev, shape, dt):
+    """gemm_nt_wide with an A_lo sweep (split activations), all three sweeps (+ split weights) and the hi + lo result of its
+    plain 16-bit epilogue -- the forms the dense decoders' projections use -- against float64."""
+    from perceiverio_pytorch_amd import _lib as L
+    lib = L.lib()
+    M, N, K, act, out_f32, b_lo, c_lo = shape
+    tdt = torch.float16 if dt == "f16" else torch.bfloat16
+    g = torch.Generator(device="cpu").manual_seed(M + 3 * N + K)
+    Af = torch.randn(M, K, generator=g) * 2.0
+    Ahi = Af.to(tdt)
+    Alo = (Af - Ahi.float()).to(tdt)
+    Bf = torch.randn(N, K, generator=g) / K ** 0.5
+    Bhi = Bf.to(tdt)
+    Blo = (Bf - Bhi.float()).to(tdt)
+    bias = torch.randn(N, generator=g)
+    ldc = N if out_f32 else (N + 7) // 8 * 8
+    Cd = torch.full((M, ldc), float("nan"), dtype=torch.float32 if out_f32 else tdt, device=dev)
+    Cl = torch.full_like(Cd, float("nan"))
+    Ad, Ald, Bd, Bld, bd = (x.to(dev) for x in (Ahi, Alo, Bhi, Blo, bias))
+    gm = L.Gemm()
+    gm.A, gm.A_lo, gm.B, gm.C = Ad.data_ptr(), Ald.data_ptr(), Bd.data_ptr(), Cd.data_ptr()
+    gm.B_lo = Bld.data_ptr() if b_lo else None
+    gm.C_lo = Cl.data_ptr() if c_lo else None
+    gm.M, gm.N, gm.K = M, N, K
+    gm.lda, gm.ldb, gm.ldc = K, K, ldc
+    gm.batch, gm.nh = 1, 1
+    gm.bias, gm.bias_mode, gm.act, gm.alpha = bd.data_ptr(), 1, act, 1.0
+    gm.out_f32, gm.n_store = int(out_f32), ldc
+    gm.dtype = L.PIO_DT_F16 if dt == "f16" else L.PIO_DT_BF16
+    prev = lib.pio_gemm_kernel_override(2)
+    try:
+        L.check(lib.pio_gemm_nt(C.byref(gm), torch.cuda.current_stream().cuda_stream), "pio_gemm_nt")
+        torch.cuda.synchronize()
+    finally:
+        lib.pio_gemm_kernel_override(prev)
+    Aop = Ahi.double() + Alo.double()
+    Bop = Bhi.double() + (Blo.double() if b_lo else 0)
+    ref = Aop @ Bop.T
+    if b_lo:
+        ref = ref - Alo.double() @ Blo.double().T       # (the dropped lo x lo term)
+    ref = ref + bias.double()[None, :]
+    if act:
+        ref = torch.nn.functional.gelu(ref)
+    got = Cd.double().cpu()
+    if c_lo:
+        got = got + Cl.double().cpu()
+    assert torch.isfinite(got[:, :N]).all()
+    if not out_f32:
+        assert (Cd[:, N:] == 0).all(), "pad columns must be written as zeros"
+        if c_lo:
+            assert (Cl[:, N:] == 0).all(), "pad columns of the lo image must be written as zeros"
+    tol = 2e-5 if (out_f32 or c_lo) else (1e-3 if dt == "f16" else 8e-3)
+    if dt == "bf16" and (out_f32 or c_lo):
+        tol = 2e-4      # (bf16 pair: 16 mantissa bits)
+    err = (got[:, :N] - ref).abs().max() / ref.abs().max()
+    assert err <= tol, f"wide, split activations {shape} {dt}: {err:.3e}"
+
+
 TILE_SHAPES = [
     # (same fields) small / ragged problems on BOTH instantiations of the 128-tile kernel: 128x128 tiles (override 128)
     # and the 64x64 tiles small batches get automatically (override 64)

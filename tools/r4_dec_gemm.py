@@ -32,7 +32,7 @@ def run(M, N, K, act, pair_out, resid, iters=20):
     g.out_f32, g.n_store, g.dtype = 0, ldc, L.PIO_DT_F16
     st = torch.cuda.current_stream().cuda_stream
     res = []
-    for ov in (0, 64, 128, 256):
+    for ov in (0, 1, 2, 256):   # automatic, stream, wide, 256 x 256
         lib.pio_gemm_kernel_override(ov)
         try:
             for _ in range(2):
@@ -51,7 +51,11 @@ def run(M, N, K, act, pair_out, resid, iters=20):
     print(f"M={M} N={N} K={K} act={act} pair_out={pair_out} resid={resid}:  " + "   ".join(res), flush=True)
 
 
-run(182528, 512, 328, 0, False, False)     # proj_q
-run(182528, 328, 328, 1, True, False)      # fc1 (GELU, pair out)
-run(182528, 328, 328, 0, True, True)       # fc2 (residual, pair out)
-run(104192, 1026 // 2 * 2, 1088, 1, True, False)   # multimodal fc1
+if "--flow" in sys.argv:
+    run(182528, 512, 328, 0, False, False)     # proj_q
+    run(182528, 328, 328, 1, True, False)      # fc1 (GELU, pair out)
+    run(182528, 328, 328, 0, True, True)       # fc2 (residual, pair out)
+run(104192, 1028, 1088, 1, True, False)    # multimodal decoder fc1 (GELU, pair out)
+run(104192, 1028, 512, 0, False, False)    # ... a K = 512 projection, one 16-bit result
+run(32000, 1024, 1024, 1, True, False)     # ImageNet decoder fc1
+run(25600, 1280, 1280, 1, True, False)     # language-sized
