@@ -687,8 +687,12 @@ int gemm_nt_launch(const pio_gemm_t &g, hipStream_t s) {
                 const char *e = getenv("PIO_WIDE_MIN_TILES");
                 return e ? atoi(e) : 128;
             }();
+            // (a residual with the hi + lo pair of the result -- the dense decoders' fc2 -- has no streaming variant: here
+            //  rather than on gemm_nt_256)
+            // (multimodal forward 23.23 -> 22.00 ms, in-process A/B)
+            const bool pair_res = p.R && !g.out_f32 && p.C_lo;
             bool wide = g.batch == 1 && g.M >= 2048 && (double)tn256 * 256.0 <= 1.25 * p.n_store && t256 >= wide_min &&
-                        (!p.R || wide_residual() || 2 * t256 < 448);
+                        (!p.R || wide_residual() || 2 * t256 < 448 || pair_res);
             if (forced == 2) wide = true;
             if (forced == 1 || forced == 128 || forced == 256) wide = false;
             const bool fold = p.X16 || p.row_part || p.ln_part || p.ln_c || p.X16_lo || p.R16_hi || p.R16_lo;

@@ -769,7 +769,7 @@ __global__ __launch_bounds__(256) void gemm_nt_wide(const GemmParams p, int tile
                     rsq += __shfl_xor(rsq, 16);
                     rsum += __shfl_xor(rsum, 32);
                     rsq += __shfl_xor(rsq, 32);
-                    if (fq == 0 && m < p.M && o_n0 < p.N) {
+                    if (p.row_part && fq == 0 && m < p.M && o_n0 < p.N) {   // (no statistics asked: a plain pair result)
                         float *dstp = p.row_part + ((int64_t)m * (p.N >> 7) + (o_n0 >> 7)) * 2;
                         dstp[0] = rsum;
                         dstp[1] = rsq;
@@ -1010,7 +1010,11 @@ bool gemm_wide_ok(const GemmParams &p, int batch) {
     // the hi + lo pair of the result: the plain 16-bit epilogue only (not the fold forms, not fp32 out)
     if (p.C_lo && (p.out_f32 || p.ln_part || p.row_part || p.X16 || ((uintptr_t)p.C_lo & 15))) return false;
     if (p.out_f32 && (p.act != 0 || (p.C && (p.ldc & 3)))) return false;
-    if (p.R && (!p.out_f32 || !p.r_vec || p.r_rows != 0 || (p.ldr & 3))) return false;
+    // an fp32 residual: with an fp32 result, or -- the dense decoders' fc2 -- with the hi + lo pair of the result (the
+    // fold producer's epilogue without its statistics: gemm_wide_launch maps C / C_lo onto X16 / X16_lo)
+    const bool pair_res = p.R && !p.out_f32 && p.C_lo && p.C && p.act == 0 && !p.X16 && !p.row_part && !p.ln_part;
+    if (p.R && ((!p.out_f32 && !pair_res) || !p.r_vec || p.r_rows != 0 || (p.ldr & 3))) return false;
+    if (pair_res && (((uintptr_t)p.C & 15) || ((uintptr_t)p.C_lo & 15) || (p.ldc & 7))) return false;
     if (p.X16 || p.row_part || p.X16_lo || p.R16_hi || p.R16_lo) {  // LayerNorm-fold producer
         const bool pair_r = p.R16_hi || p.R16_lo;
         if (!p.X16 || !p.row_part || !p.out_f32 || (p.N & 127) || p.slot_w != 128 || (p.ld16 & 7) || ((uintptr_t)p.X16 & 15) ||
@@ -1041,6 +1045,17 @@ void gemm_wide_launch(const GemmParams &p, int dtype, hipStream_t s) {
         const char *e = getenv("PIO_WIDE_KREV");  // (read per launch: A/B switch for tools/ab_env.py)
         pk.k_rev = e ? atoi(e) : 0;
     }
+    const bool pair_res = p.R && !p.out_f32 && p.C_lo;
+    if (pair_res) {   // fp32 residual in, hi + lo pair out: the fold producer's epilogue (<0, 2, 1, 1>) without statistics
+        pk.X16 = p.C;
+        pk.X16_lo = p.C_lo;
+        pk.ld16 = p.ldc;
+        pk.C = nullptr;
+        pk.C_lo = nullptr;
+        pk.out_f32 = 1;
+        pk.row_part = nullptr;
+        pk.range_flag = nullptr;
+    }
 #define PIO_WK(DTV, ACT, OUT, R, LNF) \
     hipLaunchKernelGGL((gemm_nt_wide<DTV, ACT, OUT, R, LNF>), grid, block, 0, s, pk, tiles_m, tiles_n)
     // MFMA 32x32x16 variants of the fold GEMMs (template parameter MF): an experiment that measured level -- 7 % fewer
@@ -1067,7 +1082,7 @@ void gemm_wide_launch(const GemmParams &p, int dtype, hipStream_t s) {
         else if (mf_cons && p.act == 1) PIO_WKM(DTV, 1, 0, 0, 2);    \
         else if (mf_cons) PIO_WKM(DTV, 0, 0, 0, 2);                  \
         else if (p.row_part && p.R16_hi) PIO_WK(DTV, 0, 2, 2, 1);    \
-        else if (p.row_part) PIO_WK(DTV, 0, 2, 1, 1);                \
+        else if (p.row_part || pair_res) PIO_WK(DTV, 0, 2, 1, 1);    \
         else if (p.out_f32 && p.R) PIO_WK(DTV, 0, 2, 1, 0);          \
         else if (p.out_f32) PIO_WK(DTV, 0, 2, 0, 0);                 \
         else if (p.ln_part && p.act == 1) PIO_WK(DTV, 1, 0, 0, 2);   \

@@ -237,12 +237,14 @@ def test_gemm_nt_wide(dev, shape, dt):
 
 
 WIDE_PAIR_SHAPES = [
-    # M, N, K, act, out_f32, b_lo, c_lo      (A always hi + lo: the dense decoders' split-activation GEMMs)
-    (4096, 1024, 1024, 1, False, False, True),     # decoder fc1: GELU, hi + lo result
-    (3000, 1026, 1088, 1, False, False, True),     # ... at the multimodal decoder's widths: ragged M, N = 4 x 256 + 2
-    (2048, 1024, 512, 0, True, True, False),       # out projection / final Linear under "x2afo": three sweeps, fp32 out
-    (2304, 520, 256, 0, False, True, True),        # three sweeps, hi + lo result, edge tiles
-    (2048, 512, 128, 0, False, False, False),      # two sweeps, one 16-bit result
+    # M, N, K, act, out_f32, b_lo, c_lo, resid      (A always hi + lo: the dense decoders' split-activation GEMMs)
+    (4096, 1024, 1024, 1, False, False, True, False),     # decoder fc1: GELU, hi + lo result
+    (3000, 1026, 1088, 1, False, False, True, False),     # ... at the multimodal decoder's widths: ragged M, N = 4 x 256 + 2
+    (2048, 1024, 512, 0, True, True, False, False),       # out projection / final Linear under "x2afo": three sweeps, fp32 out
+    (2304, 520, 256, 0, False, True, True, False),        # three sweeps, hi + lo result, edge tiles
+    (2048, 512, 128, 0, False, False, False, False),      # two sweeps, one 16-bit result
+    (4096, 1024, 1024, 0, False, False, True, True),      # decoder fc2: fp32 residual in, hi + lo result
+    (3000, 1032, 1088, 0, False, False, True, True),      # ... ragged, at the multimodal decoder's widths
 ]
 
 
@@ -253,7 +255,7 @@ def test_gemm_nt_wide_split_activations(dev, shape, dt):
     plain 16-bit epilogue -- the forms the dense decoders' projections use -- against float64."""
     from perceiverio_pytorch_amd import _lib as L
     lib = L.lib()
-    M, N, K, act, out_f32, b_lo, c_lo = shape
+    M, N, K, act, out_f32, b_lo, c_lo, resid = shape
     tdt = torch.float16 if dt == "f16" else torch.bfloat16
     g = torch.Generator(device="cpu").manual_seed(M + 3 * N + K)
     Af = torch.randn(M, K, generator=g) * 2.0
@@ -275,6 +277,10 @@ def test_gemm_nt_wide_split_activations(dev, shape, dt):
     gm.lda, gm.ldb, gm.ldc = K, K, ldc
     gm.batch, gm.nh = 1, 1
     gm.bias, gm.bias_mode, gm.act, gm.alpha = bd.data_ptr(), 1, act, 1.0
+    Rm = torch.randn(M, (N + 3) // 4 * 4, generator=g)
+    Rd = Rm.to(dev)
+    if resid:
+        gm.R, gm.ldr = Rd.data_ptr(), Rm.shape[1]
     gm.out_f32, gm.n_store = int(out_f32), ldc
     gm.dtype = L.PIO_DT_F16 if dt == "f16" else L.PIO_DT_BF16
     prev = lib.pio_gemm_kernel_override(2)
@@ -291,6 +297,8 @@ def test_gemm_nt_wide_split_activations(dev, shape, dt):
     ref = ref + bias.double()[None, :]
     if act:
         ref = torch.nn.functional.gelu(ref)
+    if resid:
+        ref = ref + Rm[:, :N].double()
     got = Cd.double().cpu()
     if c_lo:
         got = got + Cl.double().cpu()
