@@ -11,7 +11,7 @@ namespace pio {
 int padc_min() {
     static const int v = [] {
         const char *e = getenv("PIO_PADC_MIN");
-        return e ? atoi(e) : 512;
+        return e ? atoi(e) : 256;
     }();
     return v;
 }

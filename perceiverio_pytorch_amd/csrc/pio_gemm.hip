@@ -691,7 +691,11 @@ int gemm_nt_launch(const pio_gemm_t &g, hipStream_t s) {
             //  rather than on gemm_nt_256)
             // (multimodal forward 23.23 -> 22.00 ms, in-process A/B)
             const bool pair_res = p.R && !g.out_f32 && p.C_lo;
-            bool wide = g.batch == 1 && g.M >= 2048 && (double)tn256 * 256.0 <= 1.25 * p.n_store && t256 >= wide_min &&
+            // (N = 384 = 1.5 tile columns: a third of the MFMAs multiply padding and the kernel still beats the 128 x 128
+            //  tile's exact three columns -- 182 528 x 384 x 384, split activations, GELU, pair out: 204 against 291 us)
+            const bool fill_ok = (double)tn256 * 256.0 <= 1.25 * p.n_store ||
+                                 (p.n_store >= 384 && (double)tn256 * 256.0 <= 1.34 * p.n_store);
+            bool wide = g.batch == 1 && g.M >= 2048 && fill_ok && t256 >= wide_min &&
                         (!p.R || wide_residual() || 2 * t256 < 448 || pair_res);
             if (forced == 2) wide = true;
             if (forced == 1 || forced == 128 || forced == 256) wide = false;

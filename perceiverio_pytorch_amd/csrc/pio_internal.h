@@ -48,10 +48,11 @@ template <> struct Op<PIO_DT_BF16> {
 static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 static inline int pad8(int c) { return (c + 7) & ~7; }
 // Pitch (elements) of a CHANNEL axis in the 16-bit operand arrays = the K of the GEMM that reads them: a multiple of 8
-// (one 16-byte DMA piece); from 512 channels on a multiple of 64, which the staged kernels (gemm_nt_wide / _stream:
+// (one 16-byte DMA piece); from 256 channels on a multiple of 64, which the staged kernels (gemm_nt_wide / _stream:
 // whole 64-deep K slices) require -- the multimodal decoder's 1026-channel queries run on 1088 (+5 % K) and its
-// GEMMs 15-25 % faster for it (tools/mm_dec_gemm_bench.py).  Head dims and key counts keep pad8.
-int padc_min();  // 512 (env PIO_PADC_MIN: experiments)
+// GEMMs 15-25 % faster for it (tools/mm_dec_gemm_bench.py); the flow decoder's 322 channels on 384 (round 4: its
+// 182 528-row projections then run on gemm_nt_wide, 20-30 % faster: DESIGN_LOG R4.15).  Head dims and key counts keep pad8.
+int padc_min();  // 256 (env PIO_PADC_MIN: experiments)
 static inline int padc(int c) { return c >= padc_min() ? (c + 63) & ~63 : (c + 7) & ~7; }
 
 // carve helper for caller-provided workspaces (256-byte aligned pieces)

@@ -214,7 +214,7 @@ def pad8(c: int) -> int:
 
 
 def padc(c: int) -> int:
-    """Pitch of a CHANNEL axis in the 16-bit operand arrays (csrc/pio_internal.h padc): a multiple of 8, from 512
+    """Pitch of a CHANNEL axis in the 16-bit operand arrays (csrc/pio_internal.h padc): a multiple of 8, from 256
     channels on a multiple of 64 (the staged GEMM kernels read whole 64-deep K slices)."""
     return int(L.lib().pio_padc(int(c)))
 

@@ -40,7 +40,7 @@ def test_host_side_queries_need_no_gpu():
     lib = L.lib()
     assert lib.pio_version() == 100
     assert lib.pio_pad8(322) == 328 and lib.pio_pad8(8) == 8
-    assert [lib.pio_padc(c) for c in (322, 504, 512, 1026, 1280)] == [328, 504, 512, 1088, 1280]
+    assert [lib.pio_padc(c) for c in (96, 250, 322, 504, 512, 1026, 1280)] == [96, 256, 384, 512, 512, 1088, 1280]
     assert lib.pio_packed_weight_bytes(1024, 1024, 8, 1) == 1024 * 1024 * 2
     assert lib.pio_packed_weight_bytes(322, 322, 1, 1) == 328 * 328 * 2
     assert lib.pio_packed_weight_bytes(10, 10, 3, 1) == 0          # not divisible by the head count

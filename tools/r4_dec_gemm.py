@@ -51,6 +51,11 @@ def run(M, N, K, act, pair_out, resid, iters=20):
     print(f"M={M} N={N} K={K} act={act} pair_out={pair_out} resid={resid}:  " + "   ".join(res), flush=True)
 
 
+if "--flow384" in sys.argv:
+    run(182528, 384, 384, 1, True, False)      # fc1 with 322 padded to 384 (PIO_PADC_MIN=256)
+    run(182528, 384, 384, 0, True, True)       # fc2
+    run(182528, 512, 384, 0, False, False)     # proj_q
+    sys.exit(0)
 if "--flow" in sys.argv:
     run(182528, 512, 328, 0, False, False)     # proj_q
     run(182528, 328, 328, 1, True, False)      # fc1 (GELU, pair out)
