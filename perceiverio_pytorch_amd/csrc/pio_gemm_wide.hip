@@ -233,17 +233,20 @@ __global__ __launch_bounds__(256) void gemm_nt_wide(const GemmParams p, int tile
     const char *ia = nullptr, *ib = nullptr;  // wave-uniform bases: the DMA is "sgpr base + vgpr offset"
     char *isb = nullptr;
     int istep = 0, ibo = 0;
+    // the DMA's position inside its tile as RUNNING state (a phase is 64 MFMAs: a dozen more scalar instructions per phase
+    // to re-derive sweep, slice and operand offsets from dph cost the layer's GEMMs 1.5 %): K slice of the current sweep,
+    // the sweep's operand bases
+    int dk0 = 0;
+    const T *swA = (const T *)p.A, *swB = (const T *)p.B;
     auto issue_begin = [&]() {
         if (dj < ntl) {
             // second sweep: the same A slices against B_lo.  k_rev: the workgroup's odd tiles run the K range backwards --
             // in the blocked walk consecutive tiles of a workgroup share their A panel, and the slices a tile used LAST
             // are the ones still in the XCD's L2 when the next tile starts (the panel as a whole is not: a round of
             // 8 x 4 tiles streams 6 MB through a 4 MB L2)
-            const int sw = (dph >= nphK) + (dph >= 2 * nphK);   // sweep
-            const int kph0 = dph - sw * nphK;
-            const int kph = (p.k_rev && (dj & 1)) ? nphK - 1 - kph0 : kph0;
-            ia = (const char *)((const T *)p.A + (sw == 0 ? 0 : (sw == 1 ? p.dA1 : p.dA2)) + kph * W_BK);
-            ib = (const char *)((const T *)p.B + (sw == 0 ? 0 : (sw == 1 ? p.dB1 : p.dB2)) + kph * W_BK);
+            const int kph = (p.k_rev && (dj & 1)) ? nphK - 1 - dk0 : dk0;
+            ia = (const char *)(swA + kph * W_BK);
+            ib = (const char *)(swB + kph * W_BK);
             isb = smem + dslot * W_STAGE + wave * 4096;
             istep = 1024;
             ibo = W_AB;
@@ -265,9 +268,21 @@ __global__ __launch_bounds__(256) void gemm_nt_wide(const GemmParams p, int tile
     };
     auto issue_end = [&]() {
         dslot = (dslot + 1) & 3;
-        if (dj < ntl && ++dph == dnph) {
-            dph = 0;
-            if (++dj < ntl) dma_tile(dj);
+        if (dj < ntl) {
+            ++dph;
+            if (++dk0 == nphK) {   // next sweep of this tile (or the next tile: reset below)
+                dk0 = 0;
+                const bool second = dph == nphK;
+                swA = (const T *)p.A + (second ? p.dA1 : p.dA2);
+                swB = (const T *)p.B + (second ? p.dB1 : p.dB2);
+            }
+            if (dph == dnph) {
+                dph = 0;
+                dk0 = 0;
+                swA = (const T *)p.A;
+                swB = (const T *)p.B;
+                if (++dj < ntl) dma_tile(dj);
+            }
         }
     };
 
