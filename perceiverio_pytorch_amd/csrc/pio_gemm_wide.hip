@@ -200,8 +200,12 @@ __global__ __launch_bounds__(256) void gemm_nt_wide(const GemmParams p, int tile
     const int nphK = p.K / W_BK;
     // (p.npass sweeps in general -- (A, B) [, (A, B_lo)] [, (A_lo, B)]: split activations and / or split weights -- each at
     //  its operand offsets dA / dB; only the B_lo-only form knows columns without a second image)
+    // GEN: the instantiations the general form is for (plain epilogues; the fp32-residual producer form of the decoders'
+    // fc2).  The latent stack's fold kernels keep the two-way form they were tuned with: the general bookkeeping cost them
+    // 0.4-1.6 % (same box, rocprofv3).
+    constexpr bool GEN = LNF == 0 || RES == 1;
     auto nph_of = [&](int tn) {
-        if (p.npass == 2 && p.dA1 == 0) return tn * W_BN >= p.lo_n0 ? 2 * nphK : nphK;
+        if (!GEN || (p.npass == 2 && p.dA1 == 0)) return (p.npass == 2 && tn * W_BN >= p.lo_n0) ? 2 * nphK : nphK;
         return p.npass * nphK;
     };
 
@@ -244,9 +248,16 @@ __global__ __launch_bounds__(256) void gemm_nt_wide(const GemmParams p, int tile
             // in the blocked walk consecutive tiles of a workgroup share their A panel, and the slices a tile used LAST
             // are the ones still in the XCD's L2 when the next tile starts (the panel as a whole is not: a round of
             // 8 x 4 tiles streams 6 MB through a 4 MB L2)
-            const int kph = (p.k_rev && (dj & 1)) ? nphK - 1 - dk0 : dk0;
-            ia = (const char *)(swA + kph * W_BK);
-            ib = (const char *)(swB + kph * W_BK);
+            if constexpr (GEN) {
+                const int kph = (p.k_rev && (dj & 1)) ? nphK - 1 - dk0 : dk0;
+                ia = (const char *)(swA + kph * W_BK);
+                ib = (const char *)(swB + kph * W_BK);
+            } else {
+                const int kph0 = dph < nphK ? dph : dph - nphK;
+                const int kph = (p.k_rev && (dj & 1)) ? nphK - 1 - kph0 : kph0;
+                ia = (const char *)((const T *)p.A + kph * W_BK);
+                ib = (const char *)((const T *)p.B + (dph < nphK ? 0 : p.dB1) + kph * W_BK);
+            }
             isb = smem + dslot * W_STAGE + wave * 4096;
             istep = 1024;
             ibo = W_AB;
@@ -268,7 +279,12 @@ __global__ __launch_bounds__(256) void gemm_nt_wide(const GemmParams p, int tile
     };
     auto issue_end = [&]() {
         dslot = (dslot + 1) & 3;
-        if (dj < ntl) {
+        if constexpr (!GEN) {
+            if (dj < ntl && ++dph == dnph) {
+                dph = 0;
+                if (++dj < ntl) dma_tile(dj);
+            }
+        } else if (dj < ntl) {
             ++dph;
             if (++dk0 == nphK) {   // next sweep of this tile (or the next tile: reset below)
                 dk0 = 0;
@@ -1018,6 +1034,8 @@ bool gemm_wide_ok(const GemmParams &p, int batch) {
     // a second sweep against B_lo only (weights as hi + lo, single activations) may start at a 256-aligned column; the
     // sweeps with an A_lo image (split activations: dA1 or dA2) cover every column
     const bool b_lo_only = p.npass == 2 && p.dA1 == 0;
+    // (the fold forms run the two-way sweep code: B_lo only)
+    if (!b_lo_only && p.npass > 1 && (p.ln_part || p.ln_c || p.R16_hi || p.R16_lo || (p.row_part && !p.R))) return false;
     if (b_lo_only && (p.dB1 == 0 || p.lo_n0 < 0 || (p.lo_n0 % W_BN))) return false;
     if (!b_lo_only && p.lo_n0 != 0) return false;
     if (p.K < 4 * W_BK || (p.K % (2 * W_BK))) return false;
